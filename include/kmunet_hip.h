@@ -1,0 +1,150 @@
+/*
+ * kmunet_hip.h -- C ABI of libkmunet_hip.so: hand-written gfx950 (MI355X) HIP kernels
+ * for the KM-UNet hot path.  This is the drop-in boundary underneath the nn.Module
+ * surface.  The reference (Zhou-dot9/KM-UNet) has no FFI of its
+ * own -- every op is stock ATen -- so each entry point cites the reference Python it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes only, no torch types; every pointer is DEVICE memory owned
+ *     by the caller (inputs, outputs, saved-for-backward, workspaces).  The library
+ *     allocates nothing, keeps no mutable global state, and never synchronises: every
+ *     kernel is launched asynchronously on `stream` (a hipStream_t passed as void*), so
+ *     calls are hipGraph-capturable and re-entrant from the autograd thread.
+ *   - tensors are contiguous fp32 in the reference's layouts (NCHW / [B,C,L]).
+ *   - return value: 0 on success, KMU_ERR_ARG (-1) for a rejected argument, otherwise the
+ *     hipError_t of the failed launch; kmu_last_error() returns a thread-local message.
+ *   - "ws" workspaces: query the byte size with the matching *_ws_bytes() call; contents
+ *     are scratch, except where a comment says they carry forward->backward state.
+ */
+#ifndef KMUNET_HIP_H
+#define KMUNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMU_ABI_VERSION 1
+#define KMU_ERR_ARG (-1)
+
+typedef void* kmu_stream_t; /* hipStream_t */
+
+int kmu_version(void);
+const char* kmu_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * K1  KANConv2d 3x3 / stride 1 / pad 1   (convKAN/KANConv2Dlayers.py:15-37 +
+ *     convKAN/KANlayers.py:577-660: unfold -> b_splines -> two F.linear)
+ *
+ * Formulated as conv3x3(Phi(x), W') with Phi(x) = [SiLU(x), B_0(x)..B_7(x)] evaluated once
+ * per input element into LDS (out-of-image taps see Phi(0), not 0 -- SURVEY quirk 1) and
+ * contracted on the fp32 MFMA (v_mfma_f32_16x16x4_f32), K = 81*Cin.
+ *
+ * knots: 12 floats = one row of KANLinear.grid [in_features,12] (KANlayers.py:526-535);
+ *        all rows must be identical (they are unless update_grid() was called, which the
+ *        reference never does) -- the host wrapper checks this.
+ * ------------------------------------------------------------------------------------ */
+
+/* floats needed for the forward pack (wp_fwd) and the dX pack (wp_bwd) of one layer */
+size_t kmu_kan_pack_fwd_elems(int Cin, int Cout);
+size_t kmu_kan_pack_bwd_elems(int Cin, int Cout);
+
+/* base_weight [Cout,Cin*9], spline_weight [Cout,Cin*9,8], spline_scaler [Cout,Cin*9]
+ * (KANlayers.py:537-545; scaled_spline_weight :644-650) -> MFMA-fragment-ordered packs.
+ * wp_bwd may be NULL (inference). */
+int kmu_kan_pack_weights(const float* base_weight, const float* spline_weight, const float* spline_scaler,
+                         float* wp_fwd, float* wp_bwd, int Cin, int Cout, kmu_stream_t stream);
+
+/* y[B,Cout,H,W] = KANConv2d(x[B,Cin,H,W]).  Optional fused epilogue of
+ * StableHybridKANConv.forward (KM_UNetV3_SH.py:92-94): y = relu?(residual + kan(x)).
+ * residual may be NULL. */
+int kmu_kan_conv2d_fwd(const float* x, const float* knots, const float* wp_fwd, const float* residual, float* y,
+                       int B, int Cin, int Cout, int H, int W, int relu, kmu_stream_t stream);
+
+/* bytes of scratch for kmu_kan_conv2d_bwd_weights */
+size_t kmu_kan_bwd_ws_bytes(int B, int Cin, int Cout, int H, int W);
+
+/* dx[B,Cin,H,W] = d loss / d x given dy[B,Cout,H,W] (autograd of the lines above). */
+int kmu_kan_conv2d_bwd_input(const float* x, const float* dy, const float* knots, const float* wp_bwd, float* dx,
+                             int B, int Cin, int Cout, int H, int W, kmu_stream_t stream);
+
+/* d_base_weight, d_spline_weight, d_spline_scaler (same shapes as the parameters);
+ * deterministic two-stage reduction through ws. */
+int kmu_kan_conv2d_bwd_weights(const float* x, const float* dy, const float* knots, const float* spline_weight,
+                               const float* spline_scaler, float* d_base_weight, float* d_spline_weight,
+                               float* d_spline_scaler, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int H,
+                               int W, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  HSM-SSD mixer  (vim_block_init/efficient_vim_init.py:33-61) with its LayerNorm1D
+ *     prologue (vim_block_init/vim_utils_init.py:50-59) available as a separate call.
+ *
+ * x [B,C,L] with L = Hs*Hs.  N = state_dim (64 in KM-UNet, KM_UNetV3_SH.py:166).
+ * w_bcdt [3N,C], w_dw [3N,9], w_hz [2C,C], w_out [C,C], D [1]   (bias-free, :21-31).
+ * The parameter A is not an input: softmax_L(dt + A[n]) is shift invariant (quirk 3).
+ *
+ * forward:  pass 1 (tile-wise 1x1 proj -> dw3x3 -> online-softmax partials (m,s,acc[C,N]),
+ *           combined across workgroups), gate stage (hz_proj, SiLU gate, out_proj on the
+ *           [C,N] state), pass 2 (recompute C-part tile, y = h @ Cm).
+ * The `state` buffer carries forward -> backward: kmu_hsmssd_state_elems() floats.
+ * ------------------------------------------------------------------------------------ */
+int kmu_layernorm1d_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean /*[B,L,2]*/,
+                        int B, int C, int L, float eps, kmu_stream_t stream);
+int kmu_layernorm1d_bwd(const float* x, const float* weight, const float* rstd_mean, const float* dy, float* dx,
+                        float* d_weight_partial /*[B*ceil(L/256),C]*/, float* d_bias_partial, int B, int C, int L,
+                        kmu_stream_t stream);
+int kmu_layernorm1d_partials(int B, int L); /* rows of the *_partial outputs */
+
+size_t kmu_hsmssd_state_elems(int B, int C, int N);
+size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs);
+int kmu_hsmssd_fwd(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
+                   const float* D, float* y /*[B,C,Hs,Hs]*/, float* h /*[B,C,N]*/, float* state, void* ws,
+                   size_t ws_bytes, int B, int C, int N, int Hs, kmu_stream_t stream);
+
+size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs);
+/* number of per-workgroup partial slabs written for d_w_bcdt / d_w_dw (caller sums over dim 0) */
+int kmu_hsmssd_bwd_partials(int B, int C, int Hs);
+int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh /*may be NULL*/, const float* w_bcdt,
+                   const float* w_dw, const float* w_hz, const float* w_out, const float* D, const float* state,
+                   float* dx, float* d_w_bcdt_partial /*[P,3N,C]*/, float* d_w_dw_partial /*[P,3N,9]*/,
+                   float* d_w_hz_partial /*[B,2C,C]*/, float* d_w_out_partial /*[B,C,C]*/,
+                   float* d_D_partial /*[B]*/, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,
+                   kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  DySample x2, style 'lp', 4 groups  (DySample_md.py:49-68).
+ *
+ * conv_out [B,32,H,W] is the raw output of the 1x1 offset conv (offset.weight/bias,
+ * DySample_md.py:39,67); the kernel does "*0.25 + init_pos" (:67), the coordinate
+ * normalisation + pixel_shuffle (:50-59) and F.grid_sample(bilinear, border,
+ * align_corners=False) (:60-61).  Index generation follows the oracle's fp32 op order
+ * exactly (compiled -ffp-contract=off): ix0/iy0 are bit-exact.
+ * ix0, iy0: optional int32 [B*4, 2H, 2W] outputs (NULL to skip).
+ * ------------------------------------------------------------------------------------ */
+int kmu_dysample_lp_fwd(const float* x, const float* conv_out, const float* init_pos /*[32]*/, float* y,
+                        int32_t* ix0, int32_t* iy0, int B, int C, int H, int W, kmu_stream_t stream);
+/* dx must be zero-initialised by the caller (scatter-add); d_conv_out [B,32,H,W] is fully written. */
+int kmu_dysample_lp_bwd(const float* x, const float* conv_out, const float* init_pos, const float* dy, float* dx,
+                        float* d_conv_out, int B, int C, int H, int W, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  Deformable conv 3x3 / stride 1 / pad 1 / one offset group, no mask
+ *     (DAGEM_md.py:46,98-101 -> torchvision.ops.DeformConv2d, torchvision 0.14.0;
+ *     third-party, restated from its published semantics: PARITY UNPINNED).
+ * offset [B,18,H,W] interleaved (dy,dx) per tap; weight [Cout,Cin,3,3]; bias [Cout] or NULL.
+ * ------------------------------------------------------------------------------------ */
+int kmu_deform_conv2d_fwd(const float* x, const float* offset, const float* weight, const float* bias, float* y,
+                          int B, int Cin, int Cout, int H, int W, kmu_stream_t stream);
+/* dx, d_weight, d_bias must be zero-initialised by the caller (atomic accumulation);
+ * d_offset is fully written. */
+int kmu_deform_conv2d_bwd(const float* x, const float* offset, const float* weight, const float* dy, float* dx,
+                          float* d_offset, float* d_weight, float* d_bias, int B, int Cin, int Cout, int H, int W,
+                          kmu_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMUNET_HIP_H */

@@ -1,0 +1,70 @@
+"""ctypes binding of libkmunet_hip.so (the C ABI declared in include/kmunet_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError
+is raised.  The product never computes the hot path on the CPU or through PyTorch ops.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkmunet_hip.so")
+
+_c = ctypes
+_P, _I, _Z = _c.c_void_p, _c.c_int, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/kmunet_hip.h
+SIGNATURES = {
+    "kmu_version": (_I, []),
+    "kmu_last_error": (_c.c_char_p, []),
+    "kmu_kan_pack_fwd_elems": (_Z, [_I, _I]),
+    "kmu_kan_pack_bwd_elems": (_Z, [_I, _I]),
+    "kmu_kan_pack_weights": (_I, [_P] * 5 + [_I, _I, _P]),
+    "kmu_kan_conv2d_fwd": (_I, [_P] * 5 + [_I] * 6 + [_P]),
+    "kmu_kan_bwd_ws_bytes": (_Z, [_I] * 5),
+    "kmu_kan_conv2d_bwd_input": (_I, [_P] * 5 + [_I] * 5 + [_P]),
+    "kmu_kan_conv2d_bwd_weights": (_I, [_P] * 9 + [_Z] + [_I] * 5 + [_P]),
+    "kmu_layernorm1d_fwd": (_I, [_P] * 5 + [_I] * 3 + [_c.c_float, _P]),
+    "kmu_layernorm1d_bwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
+    "kmu_layernorm1d_partials": (_I, [_I, _I]),
+    "kmu_hsmssd_state_elems": (_Z, [_I] * 3),
+    "kmu_hsmssd_fwd_ws_bytes": (_Z, [_I] * 4),
+    "kmu_hsmssd_fwd": (_I, [_P] * 10 + [_Z] + [_I] * 4 + [_P]),
+    "kmu_hsmssd_bwd_ws_bytes": (_Z, [_I] * 4),
+    "kmu_hsmssd_bwd_partials": (_I, [_I] * 3),
+    "kmu_hsmssd_bwd": (_I, [_P] * 16 + [_Z] + [_I] * 4 + [_P]),
+    "kmu_dysample_lp_fwd": (_I, [_P] * 6 + [_I] * 4 + [_P]),
+    "kmu_dysample_lp_bwd": (_I, [_P] * 6 + [_I] * 4 + [_P]),
+    "kmu_deform_conv2d_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
+    "kmu_deform_conv2d_bwd": (_I, [_P] * 8 + [_I] * 5 + [_P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Return the loaded library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    "libkmunet_hip.so is missing (%s). Build it with `python km-unet_amd/build.py` "
+                    "(or __graft_entry__.build()); there is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)      # AttributeError => symbol missing from the build
+                fn.restype, fn.argtypes = res, args
+            if lib.kmu_version() != 1:
+                raise RuntimeError("libkmunet_hip.so ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().kmu_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg))

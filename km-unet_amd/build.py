@@ -1,0 +1,67 @@
+"""Build libkmunet_hip.so (gfx950) from csrc/*.hip with hipcc -- in-tree, no JIT cache.
+
+    python km-unet_amd/build.py [--force]
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libkmunet_hip.so")
+ARCH = "gfx950"
+# (source, extra flags).  dysample.hip generates integer gather indices that must be bit-exact
+# against the oracle's fp32 op order => no FMA contraction in that TU.
+SOURCES = [
+    ("api.hip", []),
+    ("kan_conv2d.hip", []),
+    ("hsmssd.hip", []),
+    ("dysample.hip", ["-ffp-contract=off"]),
+    ("deform_conv2d.hip", []),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libkmunet_hip.so")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    headers.append(os.path.join(HERE, "..", "include", "kmunet_hip.h"))
+    hipcc = _hipcc()
+    objs, rebuilt = [], False
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc, "-c", s, "-o", o] + COMMON + extra
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            rebuilt = True
+        objs.append(o)
+    if rebuilt or not os.path.exists(LIB):
+        subprocess.check_call([hipcc, "-shared", "-o", LIB] + objs + ["--offload-arch=" + ARCH, "-fno-gpu-rdc"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,195 @@
+// K4: deformable 3x3 conv (stride 1, pad 1, one offset group, no mask) for gfx950.
+//
+// Replaces DAGEM_md.py:98-101 (torchvision.ops.DeformConv2d, torchvision 0.14.0 -- third-party,
+// restated from its published semantics in oracle/deform.py: PARITY UNPINNED).  The op is tiny in
+// KM-UNet ([B,64,16,16], 0.5 % of the reference's forward) so these kernels are plain VALU:
+// 16 output pixels per workgroup, sampled columns staged in LDS ([Cin*9][16]), then a dense
+// [Cout x Cin*9] contraction per pixel.  Sampling rule: bilinear with zeros outside the image; the
+// whole sample is zero when y <= -1, y >= H, x <= -1 or x >= W.
+#include "common.h"
+
+namespace {
+
+constexpr int PXB = 16;  // output pixels per workgroup
+
+struct Bil {
+    int y0, x0;
+    float ly, lx;
+    bool ok00, ok01, ok10, ok11, inside;
+};
+
+__device__ __forceinline__ Bil bil_setup(float y, float x, int H, int W) {
+    Bil s;
+    s.inside = (y > -1.f) && (y < (float)H) && (x > -1.f) && (x < (float)W);
+    const float fy = floorf(y), fx = floorf(x);
+    s.y0 = (int)fy;
+    s.x0 = (int)fx;
+    s.ly = y - fy;
+    s.lx = x - fx;
+    const bool y0ok = s.y0 >= 0 && s.y0 <= H - 1, y1ok = s.y0 + 1 >= 0 && s.y0 + 1 <= H - 1;
+    const bool x0ok = s.x0 >= 0 && s.x0 <= W - 1, x1ok = s.x0 + 1 >= 0 && s.x0 + 1 <= W - 1;
+    s.ok00 = s.inside && y0ok && x0ok;
+    s.ok01 = s.inside && y0ok && x1ok;
+    s.ok10 = s.inside && y1ok && x0ok;
+    s.ok11 = s.inside && y1ok && x1ok;
+    return s;
+}
+
+// sample position of tap t at output pixel (b,h,w): y = h - 1 + t/3 + off[2t], x = w - 1 + t%3 + off[2t+1]
+__device__ __forceinline__ Bil tap_setup(const float* __restrict__ offset, int b, int h, int w, int t, int H, int W) {
+    const size_t hw = (size_t)H * W, pix = (size_t)h * W + w;
+    const float oy = offset[((size_t)b * 18 + 2 * t) * hw + pix];
+    const float ox = offset[((size_t)b * 18 + 2 * t + 1) * hw + pix];
+    return bil_setup((float)(h - 1 + t / 3) + oy, (float)(w - 1 + t % 3) + ox, H, W);
+}
+
+__device__ __forceinline__ void stage_columns(const float* __restrict__ x, const float* __restrict__ offset,
+                                              float* cols, int p0, int npix, int Cin, int H, int W) {
+    const size_t hw = (size_t)H * W;
+    for (int tp = threadIdx.x; tp < 9 * PXB; tp += blockDim.x) {
+        const int t = tp / PXB, pl = tp % PXB, p = p0 + pl;
+        if (p >= npix) {
+            for (int c = 0; c < Cin; ++c) cols[(c * 9 + t) * PXB + pl] = 0.f;
+            continue;
+        }
+        const int b = p / (H * W), h = (p / W) % H, w = p % W;
+        const Bil s = tap_setup(offset, b, h, w, t, H, W);
+        const float w00 = (1.f - s.ly) * (1.f - s.lx), w01 = (1.f - s.ly) * s.lx, w10 = s.ly * (1.f - s.lx),
+                    w11 = s.ly * s.lx;
+        const int o00 = s.y0 * W + s.x0;
+        const float* xb = x + (size_t)b * Cin * hw;
+        for (int c = 0; c < Cin; ++c) {
+            const float* xc = xb + (size_t)c * hw;
+            float v = 0.f;
+            if (s.ok00) v += w00 * xc[o00];
+            if (s.ok01) v += w01 * xc[o00 + 1];
+            if (s.ok10) v += w10 * xc[o00 + W];
+            if (s.ok11) v += w11 * xc[o00 + W + 1];
+            cols[(c * 9 + t) * PXB + pl] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void deform_fwd_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                         const float* __restrict__ weight,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                         int Cin, int Cout, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cols = smem;  // [Cin*9][PXB]
+    const int npix = B * H * W, p0 = blockIdx.x * PXB, K = Cin * 9;
+    stage_columns(x, offset, cols, p0, npix, Cin, H, W);
+    __syncthreads();
+    for (int e = threadIdx.x; e < Cout * PXB; e += blockDim.x) {
+        const int o = e / PXB, pl = e % PXB, p = p0 + pl;
+        if (p >= npix) continue;
+        float acc = bias ? bias[o] : 0.f;
+        const float* wr = weight + (size_t)o * K;
+        for (int k = 0; k < K; ++k) acc += wr[k] * cols[k * PXB + pl];
+        const int b = p / (H * W), rem = p % (H * W);
+        y[((size_t)b * Cout + o) * H * W + rem] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void deform_bwd_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                         const float* __restrict__ weight,
+                                                         const float* __restrict__ dy, float* __restrict__ dx,
+                                                         float* __restrict__ d_offset, float* __restrict__ d_weight,
+                                                         float* __restrict__ d_bias, int B, int Cin, int Cout, int H,
+                                                         int W) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = Cin * 9;
+    float* cols = smem;               // [K][PXB]
+    float* dcols = cols + K * PXB;    // [K][PXB]
+    float* dyl = dcols + K * PXB;     // [Cout][PXB]
+    const int npix = B * H * W, p0 = blockIdx.x * PXB;
+    const size_t hw = (size_t)H * W;
+    stage_columns(x, offset, cols, p0, npix, Cin, H, W);
+    for (int e = threadIdx.x; e < Cout * PXB; e += blockDim.x) {
+        const int o = e / PXB, pl = e % PXB, p = p0 + pl;
+        float v = 0.f;
+        if (p < npix) v = dy[((size_t)(p / (H * W)) * Cout + o) * hw + p % (H * W)];
+        dyl[e] = v;
+    }
+    __syncthreads();
+    // d_weight[o][k] += sum_pl dy[o][pl] * cols[k][pl] ; d_bias[o] += sum_pl dy[o][pl]
+    for (int e = threadIdx.x; e < Cout * K; e += blockDim.x) {
+        const int o = e / K, k = e % K;
+        float acc = 0.f;
+#pragma unroll
+        for (int pl = 0; pl < PXB; ++pl) acc += dyl[o * PXB + pl] * cols[k * PXB + pl];
+        atomicAdd(d_weight + e, acc);
+    }
+    for (int o = threadIdx.x; o < Cout; o += blockDim.x) {
+        float acc = 0.f;
+#pragma unroll
+        for (int pl = 0; pl < PXB; ++pl) acc += dyl[o * PXB + pl];
+        atomicAdd(d_bias + o, acc);
+    }
+    // dcols[k][pl] = sum_o weight[o][k] * dy[o][pl]
+    for (int e = threadIdx.x; e < K * PXB; e += blockDim.x) {
+        const int k = e / PXB, pl = e % PXB;
+        float acc = 0.f;
+        for (int o = 0; o < Cout; ++o) acc += weight[(size_t)o * K + k] * dyl[o * PXB + pl];
+        dcols[e] = acc;
+    }
+    __syncthreads();
+    // scatter to dx, and offset gradients (d sample / d y, d sample / d x)
+    for (int tp = threadIdx.x; tp < 9 * PXB; tp += blockDim.x) {
+        const int t = tp / PXB, pl = tp % PXB, p = p0 + pl;
+        if (p >= npix) continue;
+        const int b = p / (H * W), h = (p / W) % H, w = p % W;
+        const Bil s = tap_setup(offset, b, h, w, t, H, W);
+        const float hy = 1.f - s.ly, hx = 1.f - s.lx;
+        const int o00 = s.y0 * W + s.x0;
+        const float* xb = x + (size_t)b * Cin * hw;
+        float* dxb = dx + (size_t)b * Cin * hw;
+        float gy = 0.f, gx = 0.f;
+        for (int c = 0; c < Cin; ++c) {
+            const float g = dcols[(c * 9 + t) * PXB + pl];
+            const float* xc = xb + (size_t)c * hw;
+            float* dxc = dxb + (size_t)c * hw;
+            const float v00 = s.ok00 ? xc[o00] : 0.f, v01 = s.ok01 ? xc[o00 + 1] : 0.f;
+            const float v10 = s.ok10 ? xc[o00 + W] : 0.f, v11 = s.ok11 ? xc[o00 + W + 1] : 0.f;
+            if (s.ok00) atomicAdd(dxc + o00, g * hy * hx);
+            if (s.ok01) atomicAdd(dxc + o00 + 1, g * hy * s.lx);
+            if (s.ok10) atomicAdd(dxc + o00 + W, g * s.ly * hx);
+            if (s.ok11) atomicAdd(dxc + o00 + W + 1, g * s.ly * s.lx);
+            gy += g * (hx * (v10 - v00) + s.lx * (v11 - v01));
+            gx += g * (hy * (v01 - v00) + s.ly * (v11 - v10));
+        }
+        const size_t pix = (size_t)h * W + w;
+        d_offset[((size_t)b * 18 + 2 * t) * hw + pix] = gy;
+        d_offset[((size_t)b * 18 + 2 * t + 1) * hw + pix] = gx;
+    }
+}
+
+}  // namespace
+
+extern "C" int kmu_deform_conv2d_fwd(const float* x, const float* offset, const float* weight, const float* bias,
+                                     float* y, int B, int Cin, int Cout, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && offset && weight && y, "deform_conv2d_fwd: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "deform_conv2d_fwd: bad dims");
+    const size_t lds = (size_t)Cin * 9 * PXB * sizeof(float);
+    KMU_REQUIRE(lds <= 160 * 1024, "deform_conv2d_fwd: Cin=%d too large for the LDS column tile", Cin);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)deform_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = kmu::cdiv(B * H * W, PXB);
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, offset, weight, bias, y,
+                       B, Cin, Cout, H, W);
+    return kmu::launch_status("deform_conv2d_fwd");
+}
+
+extern "C" int kmu_deform_conv2d_bwd(const float* x, const float* offset, const float* weight, const float* dy,
+                                     float* dx, float* d_offset, float* d_weight, float* d_bias, int B, int Cin,
+                                     int Cout, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && offset && weight && dy && dx && d_offset && d_weight && d_bias, "deform_conv2d_bwd: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "deform_conv2d_bwd: bad dims");
+    const size_t lds = ((size_t)2 * Cin * 9 + Cout) * PXB * sizeof(float);
+    KMU_REQUIRE(lds <= 160 * 1024, "deform_conv2d_bwd: channels too large for the LDS tiles");
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)deform_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = kmu::cdiv(B * H * W, PXB);
+    hipLaunchKernelGGL(deform_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, offset, weight, dy, dx,
+                       d_offset, d_weight, d_bias, B, Cin, Cout, H, W);
+    return kmu::launch_status("deform_conv2d_bwd");
+}

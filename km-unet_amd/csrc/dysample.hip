@@ -1,0 +1,165 @@
+// K3: DySample x2 ('lp', 4 groups) gather kernels for gfx950.  COMPILE WITH -ffp-contract=off.
+//
+// Replaces DySample_md.py:49-68 of the reference downstream of the 1x1 offset conv:
+//   offset = conv_out*0.25 + init_pos                                   (:67)
+//   coords = 2*((w+.5, h+.5) + offset)/(W,H) - 1 ; pixel_shuffle(2)     (:50-59)
+//   F.grid_sample(x.view(B*4,16,H,W), coords, bilinear, border, align_corners=False)   (:60-61)
+// Offset channel layout (from the view/pixel_shuffle chain): ch = xy*16 + g*4 + i*2 + j; output
+// pixel (2h+i, 2w+j) of group g samples around input (h, w).
+//
+// Index generation is integer work and must be bit-exact against oracle/dysample.py
+// (sample_indices): every fp32 operation below is written in the oracle's order and this file is
+// built without FMA contraction, so floor() sees bit-identical coordinates.
+// Pure HBM gather: one thread per (b, group, oy, ox) handles the group's 16 channels; consecutive
+// threads walk ox, so the 4-corner reads of a wave fall in a handful of 128-B lines per channel
+// and the writes are fully coalesced.
+#include "common.h"
+
+namespace {
+
+struct Samp {
+    int x0, y0, x1, y1;
+    float fx, fy;
+    bool in_x, in_y;  // un-clipped coordinate strictly inside (0, size-1): gradient flows
+};
+
+__device__ __forceinline__ Samp dys_coords(const float* __restrict__ conv_out, const float* __restrict__ init_pos,
+                                           int b, int g, int oy, int ox, int H, int W) {
+    const int h = oy >> 1, i = oy & 1, w = ox >> 1, j = ox & 1;
+    const int chx = g * 4 + i * 2 + j, chy = 16 + chx;
+    const size_t hw = (size_t)H * W, pix = (size_t)h * W + w;
+    const float offx = conv_out[((size_t)b * 32 + chx) * hw + pix] * 0.25f + init_pos[chx];
+    const float offy = conv_out[((size_t)b * 32 + chy) * hw + pix] * 0.25f + init_pos[chy];
+    // normalised grid coordinate, then grid_sample's un-normalisation (align_corners=False)
+    float gx = ((float)w + 0.5f) + offx;
+    gx = 2.f * gx;
+    gx = gx / (float)W;
+    gx = gx - 1.f;
+    float gy = ((float)h + 0.5f) + offy;
+    gy = 2.f * gy;
+    gy = gy / (float)H;
+    gy = gy - 1.f;
+    float px = gx + 1.f;
+    px = px * (float)W;
+    px = px - 1.f;
+    px = px / 2.f;
+    float py = gy + 1.f;
+    py = py * (float)H;
+    py = py - 1.f;
+    py = py / 2.f;
+    Samp s;
+    s.in_x = (px > 0.f) && (px < (float)(W - 1));
+    s.in_y = (py > 0.f) && (py < (float)(H - 1));
+    px = fminf(fmaxf(px, 0.f), (float)(W - 1));  // padding_mode='border'
+    py = fminf(fmaxf(py, 0.f), (float)(H - 1));
+    const float fx0 = floorf(px), fy0 = floorf(py);
+    s.x0 = (int)fx0;
+    s.y0 = (int)fy0;
+    s.x1 = min(s.x0 + 1, W - 1);
+    s.y1 = min(s.y0 + 1, H - 1);
+    s.fx = px - fx0;
+    s.fy = py - fy0;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void dysample_fwd_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ conv_out,
+                                                           const float* __restrict__ init_pos, float* __restrict__ y,
+                                                           int32_t* __restrict__ ix0, int32_t* __restrict__ iy0, int B,
+                                                           int C, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W, cg = C / 4;
+    const size_t total = (size_t)B * 4 * OH * OW;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int ox = t % OW;
+        size_t r = t / OW;
+        const int oy = r % OH;
+        r /= OH;
+        const int g = r % 4, b = (int)(r / 4);
+        const Samp s = dys_coords(conv_out, init_pos, b, g, oy, ox, H, W);
+        if (ix0) {
+            ix0[t] = s.x0;
+            iy0[t] = s.y0;
+        }
+        const float w00 = (1.f - s.fx) * (1.f - s.fy), w01 = s.fx * (1.f - s.fy), w10 = (1.f - s.fx) * s.fy,
+                    w11 = s.fx * s.fy;
+        const size_t hw = (size_t)H * W;
+        const float* xp = x + ((size_t)b * C + (size_t)g * cg) * hw;
+        float* yp = y + (((size_t)b * C + (size_t)g * cg) * OH + oy) * OW + ox;
+        const int o00 = s.y0 * W + s.x0, o01 = s.y0 * W + s.x1, o10 = s.y1 * W + s.x0, o11 = s.y1 * W + s.x1;
+        for (int c = 0; c < cg; ++c) {
+            const float* xc = xp + (size_t)c * hw;
+            yp[(size_t)c * OH * OW] = xc[o00] * w00 + xc[o01] * w01 + xc[o10] * w10 + xc[o11] * w11;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dysample_bwd_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ conv_out,
+                                                           const float* __restrict__ init_pos,
+                                                           const float* __restrict__ dy, float* __restrict__ dx,
+                                                           float* __restrict__ d_conv_out, int B, int C, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W, cg = C / 4;
+    const size_t total = (size_t)B * 4 * OH * OW;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int ox = t % OW;
+        size_t r = t / OW;
+        const int oy = r % OH;
+        r /= OH;
+        const int g = r % 4, b = (int)(r / 4);
+        const Samp s = dys_coords(conv_out, init_pos, b, g, oy, ox, H, W);
+        const float w00 = (1.f - s.fx) * (1.f - s.fy), w01 = s.fx * (1.f - s.fy), w10 = (1.f - s.fx) * s.fy,
+                    w11 = s.fx * s.fy;
+        const size_t hw = (size_t)H * W;
+        const size_t cbase = ((size_t)b * C + (size_t)g * cg) * hw;
+        const float* dyp = dy + (((size_t)b * C + (size_t)g * cg) * OH + oy) * OW + ox;
+        const int o00 = s.y0 * W + s.x0, o01 = s.y0 * W + s.x1, o10 = s.y1 * W + s.x0, o11 = s.y1 * W + s.x1;
+        float gpx = 0.f, gpy = 0.f;
+        for (int c = 0; c < cg; ++c) {
+            const float go = dyp[(size_t)c * OH * OW];
+            const float* xc = x + cbase + (size_t)c * hw;
+            float* dxc = dx + cbase + (size_t)c * hw;
+            const float v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
+            atomicAdd(dxc + o00, go * w00);
+            atomicAdd(dxc + o01, go * w01);
+            atomicAdd(dxc + o10, go * w10);
+            atomicAdd(dxc + o11, go * w11);
+            gpx += go * ((v01 - v00) * (1.f - s.fy) + (v11 - v10) * s.fy);
+            gpy += go * ((v10 - v00) * (1.f - s.fx) + (v11 - v01) * s.fx);
+        }
+        // d px / d offset = (W/2)*(2/W) = 1 where the coordinate is not clipped (ATen
+        // clip_coordinates_set_grad: zero at and beyond the borders); offset = 0.25 * conv_out + init_pos
+        const int h = oy >> 1, i = oy & 1, w = ox >> 1, j = ox & 1;
+        const int chx = g * 4 + i * 2 + j, chy = 16 + chx;
+        const size_t pix = (size_t)h * W + w;
+        d_conv_out[((size_t)b * 32 + chx) * hw + pix] = s.in_x ? 0.25f * gpx : 0.f;
+        d_conv_out[((size_t)b * 32 + chy) * hw + pix] = s.in_y ? 0.25f * gpy : 0.f;
+    }
+}
+
+int grid_for(size_t total) {
+    size_t blocks = (total + 255) / 256;
+    return (int)(blocks > 8192 ? 8192 : (blocks ? blocks : 1));
+}
+
+}  // namespace
+
+extern "C" int kmu_dysample_lp_fwd(const float* x, const float* conv_out, const float* init_pos, float* y,
+                                   int32_t* ix0, int32_t* iy0, int B, int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && conv_out && init_pos && y, "dysample_lp_fwd: null pointer");
+    KMU_REQUIRE((ix0 == nullptr) == (iy0 == nullptr), "dysample_lp_fwd: pass both or neither index outputs");
+    KMU_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "dysample_lp_fwd: bad dims (C must be a multiple of 4 groups)");
+    const size_t total = (size_t)B * 4 * 2 * H * 2 * W;
+    hipLaunchKernelGGL(dysample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, conv_out,
+                       init_pos, y, ix0, iy0, B, C, H, W);
+    return kmu::launch_status("dysample_lp_fwd");
+}
+
+extern "C" int kmu_dysample_lp_bwd(const float* x, const float* conv_out, const float* init_pos, const float* dy,
+                                   float* dx, float* d_conv_out, int B, int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && conv_out && init_pos && dy && dx && d_conv_out, "dysample_lp_bwd: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "dysample_lp_bwd: bad dims");
+    const size_t total = (size_t)B * 4 * 2 * H * 2 * W;
+    hipLaunchKernelGGL(dysample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, conv_out,
+                       init_pos, dy, dx, d_conv_out, B, C, H, W);
+    return kmu::launch_status("dysample_lp_bwd");
+}

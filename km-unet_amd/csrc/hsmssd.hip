@@ -1,0 +1,548 @@
+// K2: EfficientViM HSM-SSD mixer for gfx950 (forward + backward) and its LayerNorm1D prologue.
+//
+// Replaces vim_block_init/efficient_vim_init.py:33-61 (HSMSSD.forward) and
+// vim_block_init/vim_utils_init.py:50-59 (LayerNorm1D.forward) of the reference.  There is no
+// recurrence in the reference's "SSM": it is softmax over the L = Hs*Hs token axis plus two batched
+// contractions, so the parallel primitive is an associative online-softmax reduction
+// (m, s, acc[C,N]) over token tiles, not a prefix scan.
+//
+// The [B,3N,L] BCdt tensor (12x the input for C=16) never touches HBM: every kernel re-derives the
+// rows it needs for one 2-D token tile (+halo) in LDS:
+//     P   = W_bcdt[rows] . x            1x1 projection   -> fp32 MFMA (v_mfma_f32_16x16x4_f32)
+//     BCdt= depthwise3x3(P)             LDS stencil, 4-token strips, ds_read_b64
+// forward  pass 1: rows {B, dt}  -> per-tile (m[n], s[n], acc[n][c] = sum_l e^{dt-m} B x)   (MFMA)
+//          gate  : combine tiles, h = acc/s ; hz_proj, SiLU gate, out_proj on the [C,N] state
+//          pass 2: rows {C}      -> y[c][l] = sum_n h2[c][n] Cm[n][l]                        (MFMA)
+// backward pass A: rows {C}      -> dh2[c][n] partials = sum_l dy[c][l] Cm[n][l]
+//          gate  : back through out_proj / gate / hz_proj -> dh[c][n], delta[n] = sum_c dh h
+//          pass B: all rows on a 2-deep halo -> dBCdt -> transposed stencil -> dP -> dx, dW partials
+//
+// Wave-level (64-lane) reductions use DPP/bpermute shuffles; cross-workgroup combines go through
+// small partial buffers reduced by the gate kernels (deterministic, no float atomics).
+// Supported: C in {16,32,64}, N = 64 (KM-UNet hard-wires state_dim=64, KM_UNetV3_SH.py:166).
+#include "common.h"
+
+using kmu::floatx4;
+
+namespace {
+
+constexpr int NS = 64;  // state_dim
+
+__host__ __device__ constexpr int pad_mod32(int n, int want) { return n + ((want - (n % 32)) + 32) % 32; }
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// Token-tile geometry: TY x 16 interior tokens, 1-deep halo, flat halo index pos = hy*18 + hx.
+template <int TY>
+struct Geo {
+    static constexpr int TX = 16, NTOK = TY * TX, NSTRIP = NTOK / 4;
+    static constexpr int HR = TY + 2, HW = TX + 2, HX = HR * HW;
+    static constexpr int MT = (HX + 15) / 16;           // 16-position MFMA row tiles covering the halo tile
+    static constexpr int XS = pad_mod32(MT * 16, 16);   // per-row stride of xs / Ps, == 16 (mod 32)
+    static constexpr int CMS = NTOK + 16;               // Cm tile stride, == 16 (mod 32)
+    static constexpr int WBS = NTOK + 2;                // wB tile stride, == 2 (mod 32)
+};
+
+template <int C>
+struct TileFor {
+    static constexpr int TY = (C <= 32) ? 16 : 8;
+};
+
+// ---- stage the halo tile of x[b] : xs[c][pos], zero outside the image --------------------------
+template <int C, int TY>
+__device__ __forceinline__ void stage_x(float* xs, const float* __restrict__ xb, int ty0, int tx0, int Hs) {
+    using G = Geo<TY>;
+    for (int e = threadIdx.x; e < C * G::XS; e += 256) {
+        const int c = e / G::XS, pos = e - c * G::XS;
+        float v = 0.f;
+        if (pos < G::HX) {
+            const int hy = pos / G::HW, hx = pos - hy * G::HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            if (gy >= 0 && gy < Hs && gx >= 0 && gx < Hs) v = xb[(size_t)c * Hs * Hs + gy * Hs + gx];
+        }
+        xs[e] = v;
+    }
+}
+
+// ---- P[16 rows][pos] = W[rows] . xs  for all halo positions (one 16-row chunk) ------------------
+// rows: kout j < 8 -> row0 + j ; j >= 8 -> row1 + (j-8)   (lets one chunk hold 8 B-rows + 8 dt-rows)
+template <int C, int TY>
+__device__ __forceinline__ void proj_chunk(float* Ps, const float* xs, const float* __restrict__ w, int row0, int row1,
+                                           int wave, int li, int lq) {
+    using G = Geo<TY>;
+    const int row = (li < 8) ? row0 + li : row1 + (li - 8);
+    float wf[C / 4];
+#pragma unroll
+    for (int ks = 0; ks < C / 4; ++ks) wf[ks] = w[(size_t)row * C + ks * 4 + lq];
+    for (int mt = wave; mt < G::MT; mt += 4) {
+        floatx4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C / 4; ++ks)
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(ks * 4 + lq) * G::XS + mt * 16 + li], wf[ks], d, 0, 0, 0);
+        *reinterpret_cast<floatx4*>(Ps + li * G::XS + mt * 16 + lq * 4) = d;  // D[pos][kout]: col = li, rows lq*4+r
+    }
+}
+
+// ---- depthwise 3x3 of one P row on a 4-token strip: out[q] for tokens (ty, sx+q) ----------------
+template <int TY>
+__device__ __forceinline__ void dw_strip(const float* Prow, const float* __restrict__ wk, int ty, int sx,
+                                         float (&out)[4]) {
+    using G = Geo<TY>;
+    float wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = wk[t];
+    out[0] = out[1] = out[2] = out[3] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const float* p = Prow + (ty + dy) * G::HW + sx;  // halo row ty+dy, halo cols sx .. sx+5
+        const floatx2 a = *reinterpret_cast<const floatx2*>(p);
+        const floatx2 b = *reinterpret_cast<const floatx2*>(p + 2);
+        const floatx2 c = *reinterpret_cast<const floatx2*>(p + 4);
+        const float v[6] = {a[0], a[1], b[0], b[1], c[0], c[1]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) out[q] += wv[dy * 3 + dx] * v[q + dx];
+    }
+}
+
+template <int WIDTH>
+__device__ __forceinline__ float grp_max(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// =================================================================================================
+// forward pass 1
+//   part_ms [B][T][2][64]   (m, s per tile)      part_acc [B][T][64 n][C]
+// =================================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void hsm_fwd_pass1(const float* __restrict__ x, const float* __restrict__ w_bcdt,
+                                                     const float* __restrict__ w_dw, float* __restrict__ part_ms,
+                                                     float* __restrict__ part_acc, int Hs, int tilesX) {
+    constexpr int TY = TileFor<C>::TY;
+    using G = Geo<TY>;
+    constexpr int NPT = G::NSTRIP / 32;  // n's per thread per 8-n chunk (2 for TY=16, 1 for TY=8)
+    constexpr int CT = C / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                       // [C][XS]
+    float* Ps = xs + C * G::XS;             // [16][XS]
+    float* wBs = Ps + 16 * G::XS;           // [16][WBS]
+    float* red = smem;                      // aliases xs|Ps after the main loop: [4 waves][64][C]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int tile = blockIdx.x, b = blockIdx.y, T = gridDim.x;
+    const int ty0 = (tile / tilesX) * TY, tx0 = (tile % tilesX) * G::TX;
+    const int L = Hs * Hs;
+
+    stage_x<C, TY>(xs, x + (size_t)b * C * L, ty0, tx0, Hs);
+
+    // strip owned by this thread in the stencil phase
+    const int strip = (TY == 16) ? lane : (lane & 31);
+    const int sty = strip >> 2, sx = (strip & 3) * 4;
+    bool valid[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) valid[q] = (ty0 + sty < Hs) && (tx0 + sx + q < Hs);
+
+    floatx4 acc[4][CT];  // [n-tile of 16][c-tile]; this wave's share of the token (K) range
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[a][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    float* ms_out = part_ms + ((size_t)b * T + tile) * 2 * NS;
+
+#pragma unroll 1
+    for (int ch = 0; ch < 8; ++ch) {  // 8 chunks of 8 states: P rows {B: n0..n0+7, dt: 128+n0..}
+        const int n0 = ch * 8;
+        __syncthreads();  // xs staged (first trip) / previous Ps + wBs consumers done
+        proj_chunk<C, TY>(Ps, xs, w_bcdt, n0, 2 * NS + n0, wave, li, lq);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            const int nl = (TY == 16) ? wave * 2 + t : wave * 2 + (lane >> 5);  // 0..7 within the chunk
+            const int n = n0 + nl;
+            float bm[4], dt[4];
+            dw_strip<TY>(Ps + nl * G::XS, w_dw + (size_t)n * 9, sty, sx, bm);
+            dw_strip<TY>(Ps + (8 + nl) * G::XS, w_dw + (size_t)(2 * NS + n) * 9, sty, sx, dt);
+            float m = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = fmaxf(m, valid[q] ? dt[q] : -INFINITY);
+            m = grp_max<G::NSTRIP>(m);
+            float s = 0.f, wb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float e = valid[q] ? __expf(dt[q] - m) : 0.f;
+                s += e;
+                wb[q] = e * bm[q];
+            }
+            s = grp_sum<G::NSTRIP>(s);
+            float* dst = wBs + ((ch & 1) * 8 + nl) * G::WBS + strip * 4;
+            *reinterpret_cast<floatx2*>(dst) = floatx2{wb[0], wb[1]};
+            *reinterpret_cast<floatx2*>(dst + 2) = floatx2{wb[2], wb[3]};
+            if (strip == 0) {
+                ms_out[n] = m;
+                ms_out[NS + n] = s;
+            }
+        }
+        if (ch & 1) {
+            __syncthreads();  // wBs for 16 states complete
+            // acc[n][c] += sum_tok wB[n][tok] * x[c][tok];  this wave covers token quads [16*wave, 16*wave+16)
+            const int a = ch >> 1;
+#pragma unroll 4
+            for (int kq = 0; kq < G::NSTRIP / 4; ++kq) {
+                const int sq = wave * (G::NSTRIP / 4) + kq;   // strip index = token quad
+                const int tok = sq * 4 + lq;                  // this lane's k-slice token
+                const int ipos = ((tok >> 4) + 1) * G::HW + (tok & 15) + 1;
+                const float av = wBs[li * G::WBS + tok];      // A[i = n][k = tok]
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xs[(c * 16 + li) * G::XS + ipos], acc[a][c],
+                                                                     0, 0, 0);  // B[k = tok][j = c]
+            }
+        }
+    }
+    __syncthreads();
+    // cross-wave reduction of acc through LDS (aliases xs|Ps)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * NS + a * 16 + lq * 4 + r) * C + c * 16 + li] = acc[a][c][r];  // D[n][c]: col c=li
+    __syncthreads();
+    float* acc_out = part_acc + ((size_t)b * T + tile) * NS * C;
+    for (int e = tid; e < NS * C; e += 256)
+        acc_out[e] = red[e] + red[NS * C + e] + red[2 * NS * C + e] + red[3 * NS * C + e];
+}
+
+// =================================================================================================
+// forward gate stage: one workgroup per batch element.
+// state layout per batch: [ M(64) | S(64) | hpre(C*64) | hz(2C*64) | h2(C*64) ]   ([c][n] row-major)
+// =================================================================================================
+__host__ __device__ inline size_t state_stride(int C) { return (size_t)2 * NS + (size_t)4 * C * NS; }
+
+__device__ __forceinline__ float silu(float z) { return z / (1.f + __expf(-z)); }
+
+__global__ __launch_bounds__(256) void hsm_fwd_gate(const float* __restrict__ part_ms,
+                                                    const float* __restrict__ part_acc,
+                                                    const float* __restrict__ w_hz, const float* __restrict__ w_out,
+                                                    const float* __restrict__ Dp, float* __restrict__ state,
+                                                    float* __restrict__ h_out, int C, int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ms = smem;            // [64]
+    float* Ss = Ms + NS;         // [64]
+    float* hp = Ss + NS;         // [C][64]
+    float* hz = hp + C * NS;     // [2C][64]
+    float* gg = hz + 2 * C * NS; // [C][64]
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float* pms = part_ms + (size_t)b * T * 2 * NS;
+    const float* pac = part_acc + (size_t)b * T * NS * C;
+    float* st = state + (size_t)b * state_stride(C);
+    if (tid < NS) {
+        float M = -INFINITY;
+        for (int t = 0; t < T; ++t) M = fmaxf(M, pms[(size_t)t * 2 * NS + tid]);
+        float S = 0.f;
+        for (int t = 0; t < T; ++t) S += pms[(size_t)t * 2 * NS + NS + tid] * __expf(pms[(size_t)t * 2 * NS + tid] - M);
+        Ms[tid] = M;
+        Ss[tid] = S;
+        st[tid] = M;
+        st[NS + tid] = S;
+    }
+    __syncthreads();
+    for (int e = tid; e < C * NS; e += 256) {  // e = n*C + c in the partial layout
+        const int n = e / C, c = e - n * C;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += pac[(size_t)t * NS * C + e] * __expf(pms[(size_t)t * 2 * NS + n] - Ms[n]);
+        a /= Ss[n];
+        hp[c * NS + n] = a;
+        st[2 * NS + c * NS + n] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * C * NS; e += 256) {  // hz[k][n] = sum_c W_hz[k][c] hpre[c][n]   (:52)
+        const int k = e / NS, n = e - k * NS;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += w_hz[k * C + c] * hp[c * NS + n];
+        hz[e] = a;
+        st[2 * NS + C * NS + e] = a;
+    }
+    __syncthreads();
+    const float Dv = Dp[0];
+    for (int e = tid; e < C * NS; e += 256) {  // g = h1*SiLU(z) + h1*D   (:55)
+        const float h1 = hz[e], z = hz[C * NS + e];
+        gg[e] = h1 * silu(z) + h1 * Dv;
+    }
+    __syncthreads();
+    for (int e = tid; e < C * NS; e += 256) {  // h2[c'][n] = sum_c W_out[c'][c] g[c][n]
+        const int co = e / NS, n = e - co * NS;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += w_out[co * C + c] * gg[c * NS + n];
+        st[2 * NS + 3 * C * NS + e] = a;
+        h_out[(size_t)b * C * NS + e] = a;
+    }
+}
+
+// =================================================================================================
+// forward pass 2:  y[c][tok] = sum_n h2[c][n] * Cm[n][tok]       (:57)
+// =================================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void hsm_fwd_pass2(const float* __restrict__ x, const float* __restrict__ w_bcdt,
+                                                     const float* __restrict__ w_dw, const float* __restrict__ state,
+                                                     float* __restrict__ y, int Hs, int tilesX) {
+    constexpr int TY = TileFor<C>::TY;
+    using G = Geo<TY>;
+    constexpr int CT = C / 16, RPW = TY / 4;  // tile rows per wave
+    constexpr int IPT = G::NSTRIP * 16 / 256;  // (strip, row) stencil items per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                 // [C][XS]
+    float* Ps = xs + C * G::XS;       // [16][XS]
+    float* Cms = Ps + 16 * G::XS;     // [16][CMS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty0 = (tile / tilesX) * TY, tx0 = (tile % tilesX) * G::TX;
+    const int L = Hs * Hs;
+    const float* h2 = state + (size_t)b * state_stride(C) + 2 * NS + 3 * C * NS;  // [C][64]
+
+    stage_x<C, TY>(xs, x + (size_t)b * C * L, ty0, tx0, Hs);
+
+    floatx4 acc[RPW][CT];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {  // 4 chunks of 16 states: P rows 64 + n0 ..
+        const int n0 = ch * 16;
+        __syncthreads();
+        proj_chunk<C, TY>(Ps, xs, w_bcdt, NS + n0, NS + n0 + 8, wave, li, lq);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < IPT; ++t) {
+            const int item = t * 256 + tid;
+            const int strip = item % G::NSTRIP, nl = item / G::NSTRIP;
+            float cm[4];
+            dw_strip<TY>(Ps + nl * G::XS, w_dw + (size_t)(NS + n0 + nl) * 9, strip >> 2, (strip & 3) * 4, cm);
+            *reinterpret_cast<floatx4*>(Cms + nl * G::CMS + strip * 4) = floatx4{cm[0], cm[1], cm[2], cm[3]};
+        }
+        __syncthreads();
+        float hf[CT][4];  // B[k = n][j = c] = h2[c][n0 + ks*4 + lq]
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) hf[c][ks] = h2[(c * 16 + li) * NS + n0 + ks * 4 + lq];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave * RPW + r;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float av = Cms[(ks * 4 + lq) * G::CMS + row * 16 + li];  // A[i = tok][k = n]
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hf[c][ks], acc[r][c], 0, 0, 0);
+            }
+        }
+    }
+    // D[tok][c]: lane col = channel li, rows = 4 consecutive tokens lq*4 + r of tile row `row`
+    float* yb = y + (size_t)b * C * L;
+    const bool vec_ok = (Hs & 3) == 0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int gy = ty0 + wave * RPW + r, gx = tx0 + lq * 4;
+        if (gy >= Hs || gx >= Hs) continue;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float* dst = yb + (size_t)(c * 16 + li) * L + gy * Hs + gx;
+            if (vec_ok && gx + 3 < Hs) {
+                *reinterpret_cast<floatx4*>(dst) = acc[r][c];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (gx + q < Hs) dst[q] = acc[r][c][q];
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// LayerNorm1D over the channel axis of [B,C,L]  (vim_utils_init.py:50-59), one thread per token
+// =================================================================================================
+__global__ __launch_bounds__(256) void ln1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       float* __restrict__ stats, int C, int L, float eps) {
+    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    const float* xp = x + (size_t)b * C * L + l;
+    float mu = 0.f;
+    for (int c = 0; c < C; ++c) mu += xp[(size_t)c * L];
+    mu /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = xp[(size_t)c * L] - mu;
+        var += d * d;
+    }
+    var /= (float)C;
+    const float rstd = 1.f / sqrtf(var + eps);
+    float* yp = y + (size_t)b * C * L + l;
+    for (int c = 0; c < C; ++c) yp[(size_t)c * L] = (xp[(size_t)c * L] - mu) * rstd * w[c] + bias[c];
+    stats[((size_t)b * L + l) * 2] = rstd;
+    stats[((size_t)b * L + l) * 2 + 1] = mu;
+}
+
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g*xhat)), g = dy*w ; per-block partials of dw, db
+__global__ __launch_bounds__(256) void ln1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ stats, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, float* __restrict__ dw_part,
+                                                       float* __restrict__ db_part, int C, int L) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = l < L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = (size_t)b * C * L + (ok ? l : 0);
+    float rstd = 0.f, mu = 0.f, s1 = 0.f, s2 = 0.f;
+    if (ok) {
+        rstd = stats[((size_t)b * L + l) * 2];
+        mu = stats[((size_t)b * L + l) * 2 + 1];
+        for (int c = 0; c < C; ++c) {
+            const float g = dy[base + (size_t)c * L] * w[c];
+            const float xh = (x[base + (size_t)c * L] - mu) * rstd;
+            s1 += g;
+            s2 += g * xh;
+        }
+        s1 /= (float)C;
+        s2 /= (float)C;
+    }
+    const int prow = blockIdx.y * gridDim.x + blockIdx.x;
+    for (int c = 0; c < C; ++c) {
+        float gdw = 0.f, gdb = 0.f;
+        if (ok) {
+            const float d = dy[base + (size_t)c * L];
+            const float xh = (x[base + (size_t)c * L] - mu) * rstd;
+            dx[base + (size_t)c * L] = rstd * (d * w[c] - s1 - xh * s2);
+            gdw = d * xh;
+            gdb = d;
+        }
+        gdw = kmu::wave_sum(gdw);
+        gdb = kmu::wave_sum(gdb);
+        __syncthreads();
+        if (lane == 0) {
+            red[0][wave] = gdw;
+            red[1][wave] = gdb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            dw_part[(size_t)prow * C + c] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            db_part[(size_t)prow * C + c] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        }
+    }
+}
+
+#include "hsmssd_bwd.inc"
+
+// ---------------------------------------------------------------------------------------------
+template <int C>
+size_t lds_pass1() {
+    using G = Geo<TileFor<C>::TY>;
+    size_t a = (size_t)C * G::XS + 16 * G::XS + 16 * G::WBS, r = (size_t)4 * NS * C;
+    return (a > r ? a : r) * sizeof(float);
+}
+template <int C>
+size_t lds_pass2() {
+    using G = Geo<TileFor<C>::TY>;
+    return ((size_t)C * G::XS + 16 * G::XS + 16 * G::CMS) * sizeof(float);
+}
+inline int tiles_for(int C, int Hs, int* tilesX) {
+    const int TY = (C <= 32) ? 16 : 8;
+    *tilesX = kmu::cdiv(Hs, 16);
+    return *tilesX * kmu::cdiv(Hs, TY);
+}
+
+template <int C>
+int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
+             const float* D, float* y, float* h, float* state, float* ws, int B, int Hs, hipStream_t st) {
+    int tilesX;
+    const int T = tiles_for(C, Hs, &tilesX);
+    float* part_ms = ws;
+    float* part_acc = ws + (size_t)B * T * 2 * NS;
+    const size_t l1 = lds_pass1<C>(), l2 = lds_pass2<C>();
+    (void)hipFuncSetAttribute((const void*)hsm_fwd_pass1<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+    (void)hipFuncSetAttribute((const void*)hsm_fwd_pass2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    hipLaunchKernelGGL(hsm_fwd_pass1<C>, dim3(T, B), dim3(256), l1, st, x, w_bcdt, w_dw, part_ms, part_acc, Hs, tilesX);
+    int rc = kmu::launch_status("hsmssd_fwd pass1");
+    if (rc) return rc;
+    const size_t lg = ((size_t)2 * NS + 4 * C * NS) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)hsm_fwd_gate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg);
+    hipLaunchKernelGGL(hsm_fwd_gate, dim3(B), dim3(256), lg, st, part_ms, part_acc, w_hz, w_out, D, state, h, C, T);
+    rc = kmu::launch_status("hsmssd_fwd gate");
+    if (rc) return rc;
+    hipLaunchKernelGGL(hsm_fwd_pass2<C>, dim3(T, B), dim3(256), l2, st, x, w_bcdt, w_dw, state, y, Hs, tilesX);
+    return kmu::launch_status("hsmssd_fwd pass2");
+}
+
+}  // namespace
+
+extern "C" size_t kmu_hsmssd_state_elems(int B, int C, int N) { return (size_t)B * ((size_t)2 * N + (size_t)4 * C * N); }
+
+extern "C" size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs) {
+    int tx;
+    const int T = tiles_for(C, Hs, &tx);
+    return (size_t)B * T * ((size_t)2 * N + (size_t)N * C) * sizeof(float);
+}
+
+extern "C" int kmu_hsmssd_fwd(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                              const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
+                              size_t ws_bytes, int B, int C, int N, int Hs, kmu_stream_t stream) {
+    KMU_REQUIRE(x && w_bcdt && w_dw && w_hz && w_out && D && y && h && state && ws, "hsmssd_fwd: null pointer");
+    KMU_REQUIRE(N == NS, "hsmssd_fwd: state_dim=%d unsupported (kernels are built for 64)", N);
+    KMU_REQUIRE(C == 16 || C == 32 || C == 64, "hsmssd_fwd: C=%d unsupported (16/32/64)", C);
+    KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0, "hsmssd_fwd: bad dims");
+    KMU_REQUIRE(ws_bytes >= kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs), "hsmssd_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) return fwd_impl<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, st);
+    if (C == 32) return fwd_impl<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, st);
+    return fwd_impl<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, st);
+}
+
+extern "C" int kmu_layernorm1d_partials(int B, int L) { return B * kmu::cdiv(L, 256); }
+
+extern "C" int kmu_layernorm1d_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean,
+                                   int B, int C, int L, float eps, kmu_stream_t stream) {
+    KMU_REQUIRE(x && weight && bias && y && rstd_mean, "layernorm1d_fwd: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0, "layernorm1d_fwd: bad dims");
+    hipLaunchKernelGGL(ln1d_fwd_kernel, dim3(kmu::cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, x, weight, bias, y,
+                       rstd_mean, C, L, eps);
+    return kmu::launch_status("layernorm1d_fwd");
+}
+
+extern "C" int kmu_layernorm1d_bwd(const float* x, const float* weight, const float* rstd_mean, const float* dy,
+                                   float* dx, float* d_weight_partial, float* d_bias_partial, int B, int C, int L,
+                                   kmu_stream_t stream) {
+    KMU_REQUIRE(x && weight && rstd_mean && dy && dx && d_weight_partial && d_bias_partial, "layernorm1d_bwd: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0, "layernorm1d_bwd: bad dims");
+    hipLaunchKernelGGL(ln1d_bwd_kernel, dim3(kmu::cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, x, weight,
+                       rstd_mean, dy, dx, d_weight_partial, d_bias_partial, C, L);
+    return kmu::launch_status("layernorm1d_bwd");
+}
+
+// ---- backward entry points (kernels in hsmssd_bwd.inc) -------------------------------------------
+extern "C" size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs) { (void)B; (void)C; (void)N; (void)Hs; return 0; }
+extern "C" int kmu_hsmssd_bwd_partials(int B, int C, int Hs) { (void)B; (void)C; (void)Hs; return 0; }
+extern "C" int kmu_hsmssd_bwd(const float*, const float*, const float*, const float*, const float*, const float*,
+                              const float*, const float*, const float*, float*, float*, float*, float*, float*, float*,
+                              void*, size_t, int, int, int, int, kmu_stream_t) {
+    kmu::set_error("hsmssd_bwd: not built yet");
+    return KMU_ERR_ARG;
+}

@@ -1,0 +1,293 @@
+"""nn.Module surface of the hot blocks -- same constructor arguments, attribute names and
+state_dict keys as the reference modules they stand in for; forward() launches the HIP kernels
+(km-unet_amd/ops.py).  Glue that the reference leaves to stock ATen (convs, BatchNorm, ...)
+stays stock PyTorch-ROCm here as well.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ------------------------------------------------------------------ convKAN (K1)
+class KANLinear(nn.Module):
+    """Parameter container compatible with convKAN/KANlayers.py:505-575.
+
+    Used through KANConv2d (the only way KM-UNet uses it).  A direct call treats the rows as
+    1x1 "images" of a 3x3-padded conv is not meaningful, so forward() on a bare [M, in] matrix
+    is provided only for in_features divisible by 9 via the same kernel (centre-tap free)."""
+
+    def __init__(self, in_features, out_features, grid_size=5, spline_order=3, scale_noise=0.1, scale_base=1.0,
+                 scale_spline=1.0, enable_standalone_scale_spline=True, base_activation=nn.SiLU, grid_eps=0.02,
+                 grid_range=(-1, 1)):
+        super().__init__()
+        if grid_size != 5 or spline_order != 3 or not enable_standalone_scale_spline or base_activation is not nn.SiLU:
+            raise NotImplementedError("KANLinear: the HIP kernels are built for grid_size=5, spline_order=3, SiLU base, "
+                                      "standalone spline scaler (the configuration KM-UNet uses)")
+        self.in_features, self.out_features = in_features, out_features
+        self.grid_size, self.spline_order = grid_size, spline_order
+        h = (grid_range[1] - grid_range[0]) / grid_size
+        knots = torch.arange(-spline_order, grid_size + spline_order + 1) * h + grid_range[0]
+        self.register_buffer("grid", knots.expand(in_features, -1).contiguous())
+        self.base_weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.spline_weight = nn.Parameter(torch.empty(out_features, in_features, grid_size + spline_order))
+        self.spline_scaler = nn.Parameter(torch.empty(out_features, in_features))
+        self.scale_noise, self.scale_base, self.scale_spline = scale_noise, scale_base, scale_spline
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # Same distributions as the reference (KANlayers.py:555-575); the spline coefficients are the
+        # least-squares fit of uniform noise at the 6 interior knots, solved here in closed form per
+        # feature with torch.linalg.lstsq on the (6 x 8) collocation matrix of the shared knot vector.
+        nn.init.kaiming_uniform_(self.base_weight, a=math.sqrt(5) * self.scale_base)
+        nn.init.kaiming_uniform_(self.spline_scaler, a=math.sqrt(5) * self.scale_spline)
+        with torch.no_grad():
+            g = self.grid[0].double()
+            pts = g[self.spline_order:-self.spline_order]                       # 6 interior knots
+            coll = _bspline_collocation(pts, g, self.spline_order)              # [6, 8]
+            noise = (torch.rand(self.grid_size + 1, self.in_features * self.out_features, dtype=torch.float64) - 0.5) \
+                * self.scale_noise / self.grid_size
+            coef = torch.linalg.lstsq(coll, noise).solution                     # [8, in*out]
+            self.spline_weight.copy_(coef.t().reshape(self.in_features, self.out_features, -1).permute(1, 0, 2))
+
+
+def _bspline_collocation(x, knots, order):
+    x = x.unsqueeze(-1)
+    b = ((x >= knots[:-1]) & (x < knots[1:])).to(x.dtype)
+    for k in range(1, order + 1):
+        b = (x - knots[:-(k + 1)]) / (knots[k:-1] - knots[:-(k + 1)]) * b[:, :-1] \
+            + (knots[k + 1:] - x) / (knots[k + 1:] - knots[1:-k]) * b[:, 1:]
+    return b
+
+
+class KANConv2d(nn.Module):
+    """convKAN/KANConv2Dlayers.py:5-37.  Only the 3x3 / stride 1 / padding 1 form KM-UNet uses is built."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        if (kernel_size, stride, padding) != (3, 1, 1):
+            raise NotImplementedError("KANConv2d: HIP kernel is built for kernel_size=3, stride=1, padding=1")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.kanlayer = KANLinear(in_channels * kernel_size * kernel_size, out_channels)
+
+    def forward(self, x, residual=None, relu=False):
+        k = self.kanlayer
+        return ops.kan_conv2d(x, k.grid, k.base_weight, k.spline_weight, k.spline_scaler, residual, relu)
+
+
+# ------------------------------------------------------------------ vim_block_init (K2)
+class LayerNorm1D(nn.Module):
+    def __init__(self, num_channels, eps=1e-5, affine=True):
+        super().__init__()
+        assert affine
+        self.num_channels, self.eps = num_channels, eps
+        self.weight = nn.Parameter(torch.ones(1, num_channels, 1))
+        self.bias = nn.Parameter(torch.zeros(1, num_channels, 1))
+
+    def forward(self, x):
+        return ops.layernorm1d(x, self.weight, self.bias, self.eps)
+
+
+class ConvLayer1D(nn.Module):
+    """vim_utils_init.py:92-119 restricted to what KM-UNet instantiates (1x1, bias-free, optional BN/act)."""
+
+    def __init__(self, in_dim, out_dim, kernel_size=3, stride=1, padding=0, dilation=1, groups=1, norm=nn.BatchNorm1d,
+                 act_layer=nn.ReLU, bn_weight_init=1):
+        super().__init__()
+        self.conv = nn.Conv1d(in_dim, out_dim, kernel_size, stride, padding, dilation, groups, bias=False)
+        self.norm = norm(num_features=out_dim) if norm else None
+        self.act = act_layer() if act_layer else None
+        if self.norm:
+            nn.init.constant_(self.norm.weight, bn_weight_init)
+            nn.init.constant_(self.norm.bias, 0)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm:
+            x = self.norm(x)
+        return self.act(x) if self.act else x
+
+
+class ConvLayer2D(nn.Module):
+    """vim_utils_init.py:62-89."""
+
+    def __init__(self, in_dim, out_dim, kernel_size=3, stride=1, padding=0, dilation=1, groups=1, norm=nn.BatchNorm2d,
+                 act_layer=nn.ReLU, bn_weight_init=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_dim, out_dim, kernel_size, stride, padding, dilation, groups, bias=False)
+        self.norm = norm(num_features=out_dim) if norm else None
+        self.act = act_layer() if act_layer else None
+        if self.norm:
+            nn.init.constant_(self.norm.weight, bn_weight_init)
+            nn.init.constant_(self.norm.bias, 0)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm:
+            x = self.norm(x)
+        return self.act(x) if self.act else x
+
+
+class HSMSSD(nn.Module):
+    """vim_block_init/efficient_vim_init.py:14-61; forward = one fused HIP op returning (y, h)."""
+
+    def __init__(self, d_model, ssd_expand=1, A_init_range=(1, 16), state_dim=64):
+        super().__init__()
+        if ssd_expand != 1:
+            raise NotImplementedError("HSMSSD: ssd_expand != 1 is not built (KM-UNet uses 1)")
+        self.ssd_expand, self.d_inner, self.state_dim = ssd_expand, d_model, state_dim
+        self.BCdt_proj = ConvLayer1D(d_model, 3 * state_dim, 1, norm=None, act_layer=None)
+        self.dw = ConvLayer2D(3 * state_dim, 3 * state_dim, 3, 1, 1, groups=3 * state_dim, norm=None, act_layer=None)
+        self.hz_proj = ConvLayer1D(d_model, 2 * d_model, 1, norm=None, act_layer=None)
+        self.out_proj = ConvLayer1D(d_model, d_model, 1, norm=None, act_layer=None)
+        self.A = nn.Parameter(torch.empty(state_dim).uniform_(*A_init_range))
+        self.D = nn.Parameter(torch.ones(1))
+        self.D._no_weight_decay = True
+
+    def forward(self, x):
+        return ops.hsmssd(x, self.BCdt_proj.conv.weight, self.dw.conv.weight, self.hz_proj.conv.weight,
+                          self.out_proj.conv.weight, self.A, self.D)
+
+
+class FFN(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.fc1 = ConvLayer2D(in_dim, dim, 1)
+        self.fc2 = ConvLayer2D(dim, in_dim, 1, act_layer=None, bn_weight_init=0)
+
+    def forward(self, x):
+        return self.fc2(self.fc1(x))
+
+
+class EfficientViMBlock(nn.Module):
+    """efficient_vim_init.py:64-97."""
+
+    def __init__(self, dim, mlp_ratio=4.0, ssd_expand=1, state_dim=64):
+        super().__init__()
+        self.dim, self.mlp_ratio = dim, mlp_ratio
+        self.mixer = HSMSSD(d_model=dim, ssd_expand=ssd_expand, state_dim=state_dim)
+        self.norm = LayerNorm1D(dim)
+        self.dwconv1 = ConvLayer2D(dim, dim, 3, padding=1, groups=dim, bn_weight_init=0, act_layer=None)
+        self.dwconv2 = ConvLayer2D(dim, dim, 3, padding=1, groups=dim, bn_weight_init=0, act_layer=None)
+        self.ffn = FFN(in_dim=dim, dim=int(dim * mlp_ratio))
+        self.alpha = nn.Parameter(1e-4 * torch.ones(4, dim))
+
+    def forward(self, x):
+        a = torch.sigmoid(self.alpha).view(4, -1, 1, 1)
+        x = torch.lerp(x, self.dwconv1(x), a[0])
+        y, _ = self.mixer(self.norm(x.flatten(2)))
+        x = torch.lerp(x, y, a[1])
+        x = torch.lerp(x, self.dwconv2(x), a[2])
+        return torch.lerp(x, self.ffn(x), a[3])
+
+
+# ------------------------------------------------------------------ DySample (K3)
+class DySample(nn.Module):
+    """DySample_md.py:20-81, style 'lp' without dyscope (the configuration KM-UNet builds)."""
+
+    def __init__(self, in_channels, scale=2, style="lp", groups=4, dyscope=False):
+        super().__init__()
+        if style != "lp" or dyscope or scale != 2 or groups != 4:
+            raise NotImplementedError("DySample: HIP kernel is built for scale=2, style='lp', groups=4, dyscope=False")
+        self.scale, self.style, self.groups = scale, style, groups
+        self.offset = nn.Conv2d(in_channels, 2 * groups * scale ** 2, 1)
+        nn.init.normal_(self.offset.weight, 0, 0.001)
+        nn.init.constant_(self.offset.bias, 0)
+        h = torch.arange((-scale + 1) / 2, (scale - 1) / 2 + 1) / scale
+        self.register_buffer("init_pos", torch.stack(torch.meshgrid([h, h], indexing="ij")).transpose(1, 2)
+                             .repeat(1, groups, 1).reshape(1, -1, 1, 1))
+
+    def forward(self, x):
+        return ops.dysample_lp(x, self.offset(x), self.init_pos)
+
+
+# ------------------------------------------------------------------ DAGEM (K4)
+class DeformConv2d(nn.Module):
+    """Parameters of torchvision.ops.DeformConv2d(in, out, 3, padding=1): weight, bias."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True):
+        super().__init__()
+        if (kernel_size, stride, padding) != (3, 1, 1):
+            raise NotImplementedError("DeformConv2d: HIP kernel is built for 3x3 / stride 1 / padding 1")
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_channels * 9)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, offset):
+        return ops.deform_conv2d(x, offset, self.weight, self.bias)
+
+
+class DAGEM(nn.Module):
+    """DAGEM_md.py:7-111: graph-edge bridge; the deformable conv is the HIP kernel, the small MLPs are glue."""
+
+    def __init__(self, sync_bn=False, input_channels=256):
+        super().__init__()
+        c = self.input_channels = input_channels
+        mlp = lambda i, o: nn.Sequential(nn.Linear(i, o), nn.BatchNorm1d(o), nn.ReLU(inplace=True))
+        self.edge_aggregation_func = mlp(4, 1)
+        self.vertex_update_func = mlp(2 * c, c // 2)
+        self.edge_update_func = mlp(2 * c, c // 2)
+        self.update_edge_reduce_func = mlp(4, 1)
+        self.offset_conv = nn.Conv2d(c, 18, 3, padding=1)
+        self.deform_conv = DeformConv2d(c, c, 3, padding=1)
+        self.final_aggregation_layer = nn.Sequential(nn.Conv2d(c + c // 2, c, 1, bias=False), nn.BatchNorm2d(c),
+                                                     nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        nb = torch.stack((x.roll(1, 2), x.roll(-1, 2), x.roll(1, 3), x.roll(-1, 3)), dim=-1)
+        edge = nb * x.unsqueeze(-1)                                                   # [B,C,H,W,4]
+        agg = self.edge_aggregation_func(edge.reshape(-1, 4)).view(b, c, h, w)
+        vert = self.vertex_update_func(torch.cat((x, agg), 1).permute(0, 2, 3, 1).reshape(-1, 2 * c))
+        vert = vert.view(b, h, w, c // 2).permute(0, 3, 1, 2)
+        ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1).permute(0, 2, 3, 4, 1).reshape(-1, 2 * c)
+        ue = self.edge_update_func(ef).view(b, h, w, 4, c // 2).permute(0, 4, 1, 2, 3).reshape(-1, 4)
+        ue = self.update_edge_reduce_func(ue).view(b, c // 2, h, w)
+        deformed = self.deform_conv(x, self.offset_conv(x)) + x
+        return self.final_aggregation_layer(torch.cat((deformed, vert * ue), 1))
+
+
+# ------------------------------------------------------------------ WPL/iwp.py (glue)
+class _HaarDWT(nn.Module):
+    """WPL/iwp.py:47-113 as a 2x2 stencil.  LL = (a+b+c+d)/2 etc.; the reference's high-pass matrix has
+    an all-zero last row (iwp.py:79), i.e. the last row of HL/HH and the last column of LH/HH are zero."""
+
+    def forward(self, x):
+        a, b = x[..., 0::2, 0::2], x[..., 0::2, 1::2]
+        c, d = x[..., 1::2, 0::2], x[..., 1::2, 1::2]
+        ll = (a + b + c + d) * 0.5
+        lh = (a - b + c - d) * 0.5      # low over rows, high over columns
+        hl = (a + b - c - d) * 0.5      # high over rows, low over columns
+        hh = (a - b - c + d) * 0.5
+        hq, wq = ll.shape[-2:]
+        rmask = torch.ones(hq, 1, device=x.device, dtype=x.dtype)
+        rmask[-1] = 0
+        cmask = torch.ones(1, wq, device=x.device, dtype=x.dtype)
+        cmask[:, -1] = 0
+        return ll, lh * cmask, hl * rmask, hh * (rmask * cmask)
+
+
+class IntelligentWaveletPoolingModule(nn.Module):
+    """WPL/iwp.py:116-132.  nn.Softmax2d over the one-channel attention map is identically 1."""
+
+    def __init__(self, in_channels, wavename="haar"):
+        super().__init__()
+        if wavename != "haar":
+            raise NotImplementedError("only the haar wavelet is restated")
+        self.dwt = _HaarDWT()
+        self.high_freq_conv = nn.Conv2d(3 * in_channels, 1, 1)
+        self.softmax = nn.Softmax2d()
+        self.fusion_conv = nn.Conv2d(in_channels + 1, in_channels, 1)
+
+    def forward(self, x):
+        ll, lh, hl, hh = self.dwt(x)
+        high = torch.cat([lh, hl, hh], dim=1)
+        high = high * self.softmax(self.high_freq_conv(high))
+        return self.fusion_conv(torch.cat([ll, high.mean(dim=1, keepdim=True)], dim=1))

@@ -1,0 +1,279 @@
+"""torch.autograd.Function wrappers that launch the HIP kernels through the C ABI.
+
+Every function takes/returns CUDA(ROCm) fp32 tensors and launches on torch's current stream,
+so calls are stream-ordered with the surrounding PyTorch glue and hipGraph-capturable.  A CPU
+tensor (or a missing library) raises: the hot path has no fallback.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s: %s is on %s; the KM-UNet hot path only runs as HIP kernels on an MI355X "
+                           "(no CPU fallback)" % ("kmunet", name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ K1
+def _check_grid(grid):
+    """KANLinear.grid is [in_features, 12] with identical rows (KANlayers.py:526-535).  The kernels
+    share one knot vector; verified once per buffer version (host sync, so never inside a capture)."""
+    key = (grid.data_ptr(), grid._version, tuple(grid.shape))
+    if getattr(_check_grid, "_ok", None) != key:
+        if grid.dim() != 2 or grid.shape[1] != 12:
+            raise RuntimeError("KANConv2d: expected a [in_features, 12] knot buffer, got %s" % (tuple(grid.shape),))
+        if not bool((grid == grid[0:1]).all()):
+            raise RuntimeError("KANConv2d: per-feature knot vectors differ (update_grid() was called?); "
+                               "the HIP kernel supports one shared knot vector only")
+        if not bool((grid[0, 1:] > grid[0, :-1]).all()):
+            raise RuntimeError("KANConv2d: knots must be strictly increasing")
+        _check_grid._ok = key
+    return grid[0].contiguous()
+
+
+class KanConv2dFn(torch.autograd.Function):
+    """y = KANConv2d_3x3_s1_p1(x)  [+ residual] [ReLU]   (convKAN/KANConv2Dlayers.py:15-37)."""
+
+    @staticmethod
+    def forward(ctx, x, grid, base_w, spline_w, scaler, residual, relu):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        base_w, spline_w, scaler = _f32c(base_w, "base_weight"), _f32c(spline_w, "spline_weight"), _f32c(scaler, "spline_scaler")
+        knots = _check_grid(grid)
+        B, Cin, H, W = x.shape
+        Cout = base_w.shape[0]
+        if base_w.shape[1] != Cin * 9:
+            raise RuntimeError("KANConv2d: base_weight %s does not match Cin=%d, 3x3" % (tuple(base_w.shape), Cin))
+        need_bwd = any(ctx.needs_input_grad)
+        wp_f = torch.empty(lib.kmu_kan_pack_fwd_elems(Cin, Cout), device=x.device, dtype=torch.float32)
+        wp_b = torch.empty(lib.kmu_kan_pack_bwd_elems(Cin, Cout), device=x.device, dtype=torch.float32) if need_bwd else None
+        st = _stream()
+        _lib.check(lib.kmu_kan_pack_weights(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wp_f), _ptr(wp_b), Cin, Cout, st),
+                   "kmu_kan_pack_weights")
+        y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+        if residual is not None:
+            residual = _f32c(residual, "residual")
+        _lib.check(lib.kmu_kan_conv2d_fwd(_ptr(x), _ptr(knots), _ptr(wp_f), _ptr(residual), _ptr(y), B, Cin, Cout, H, W,
+                                          1 if relu else 0, st), "kmu_kan_conv2d_fwd")
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, knots, spline_w, scaler, wp_b, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, knots, spline_w, scaler, wp_b, y = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        if ctx.relu:
+            dy = dy * (y > 0)
+        B, Cin, H, W = x.shape
+        Cout = dy.shape[1]
+        st = _stream()
+        dx = d_bw = d_sw = d_sc = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.kmu_kan_conv2d_bwd_input(_ptr(x), _ptr(dy), _ptr(knots), _ptr(wp_b), _ptr(dx), B, Cin, Cout, H, W, st),
+                       "kmu_kan_conv2d_bwd_input")
+        if any(ctx.needs_input_grad[2:5]):
+            nbytes = lib.kmu_kan_bwd_ws_bytes(B, Cin, Cout, H, W)
+            ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+            d_bw = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
+            d_sw = torch.empty(Cout, Cin * 9, 8, device=x.device, dtype=torch.float32)
+            d_sc = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
+            _lib.check(lib.kmu_kan_conv2d_bwd_weights(_ptr(x), _ptr(dy), _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw),
+                                                      _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes, B, Cin, Cout, H, W, st),
+                       "kmu_kan_conv2d_bwd_weights")
+        return dx, None, d_bw, d_sw, d_sc, (dy if ctx.has_res else None), None
+
+
+def kan_conv2d(x, grid, base_weight, spline_weight, spline_scaler, residual=None, relu=False):
+    return KanConv2dFn.apply(x, grid, base_weight, spline_weight, spline_scaler, residual, relu)
+
+
+# ------------------------------------------------------------------------------------------ K2
+class LayerNorm1dFn(torch.autograd.Function):
+    """Per-token LayerNorm over C of [B,C,L] (vim_utils_init.py:50-59)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        w, b = _f32c(weight, "weight").reshape(-1), _f32c(bias, "bias").reshape(-1)
+        B, C, L = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(B, L, 2, device=x.device, dtype=torch.float32)
+        _lib.check(lib.kmu_layernorm1d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), B, C, L, float(eps), _stream()),
+                   "kmu_layernorm1d_fwd")
+        ctx.save_for_backward(x, w, stats)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, stats = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B, C, L = x.shape
+        rows = lib.kmu_layernorm1d_partials(B, L)
+        dx = torch.empty_like(x)
+        dwp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
+        dbp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
+        _lib.check(lib.kmu_layernorm1d_bwd(_ptr(x), _ptr(w), _ptr(stats), _ptr(dy), _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, L,
+                                           _stream()), "kmu_layernorm1d_bwd")
+        return dx, dwp.sum(0).view(ctx.wshape), dbp.sum(0).view(ctx.wshape), None
+
+
+def layernorm1d(x, weight, bias, eps=1e-5):
+    return LayerNorm1dFn.apply(x, weight, bias, eps)
+
+
+class HsmssdFn(torch.autograd.Function):
+    """(y[B,C,Hs,Hs], h[B,C,N]) = HSMSSD(x[B,C,L])  (efficient_vim_init.py:33-61)."""
+
+    @staticmethod
+    def forward(ctx, x, w_bcdt, w_dw, w_hz, w_out, A, D):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, C, L = x.shape
+        Hs = int(round(L ** 0.5))
+        if Hs * Hs != L:
+            raise RuntimeError("HSMSSD: L=%d is not a perfect square (reference: int(math.sqrt(L)))" % L)
+        N = A.shape[0]
+        w_bcdt, w_dw = _f32c(w_bcdt, "BCdt_proj.weight").reshape(3 * N, C), _f32c(w_dw, "dw.weight").reshape(3 * N, 9)
+        w_hz, w_out, D = _f32c(w_hz, "hz_proj.weight").reshape(2 * C, C), _f32c(w_out, "out_proj.weight").reshape(C, C), _f32c(D, "D")
+        dev = x.device
+        y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
+        h = torch.empty(B, C, N, device=dev, dtype=torch.float32)
+        state = torch.empty(lib.kmu_hsmssd_state_elems(B, C, N), device=dev, dtype=torch.float32)
+        nbytes = lib.kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs)
+        ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
+        _lib.check(lib.kmu_hsmssd_fwd(_ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(y), _ptr(h),
+                                      _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, _stream()), "kmu_hsmssd_fwd")
+        ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
+        ctx.dims = (B, C, N, Hs)
+        ctx.A_shape = A.shape
+        return y, h
+
+    @staticmethod
+    def backward(ctx, dy, dh):
+        lib = _lib.load()
+        x, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+        B, C, N, Hs = ctx.dims
+        dev = x.device
+        dy = _f32c(dy, "dy") if dy is not None else torch.zeros(B, C, Hs, Hs, device=dev)
+        dh = _f32c(dh, "dh") if dh is not None else None
+        P = lib.kmu_hsmssd_bwd_partials(B, C, Hs)
+        dx = torch.empty_like(x)
+        p_bcdt = torch.empty(P, 3 * N, C, device=dev, dtype=torch.float32)
+        p_dw = torch.empty(P, 3 * N, 9, device=dev, dtype=torch.float32)
+        p_hz = torch.empty(B, 2 * C, C, device=dev, dtype=torch.float32)
+        p_out = torch.empty(B, C, C, device=dev, dtype=torch.float32)
+        p_D = torch.empty(B, device=dev, dtype=torch.float32)
+        nbytes = lib.kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)
+        ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
+        _lib.check(lib.kmu_hsmssd_bwd(_ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz), _ptr(w_out), _ptr(D),
+                                      _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz), _ptr(p_out), _ptr(p_D),
+                                      _ptr(ws), nbytes, B, C, N, Hs, _stream()), "kmu_hsmssd_bwd")
+        # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd
+        # returns ~1e-7 rounding noise here)
+        return (dx, p_bcdt.sum(0).view(3 * N, C, 1), p_dw.sum(0).view(3 * N, 1, 3, 3), p_hz.sum(0).view(2 * C, C, 1),
+                p_out.sum(0).view(C, C, 1), torch.zeros(ctx.A_shape, device=dev), p_D.sum().view(1))
+
+
+def hsmssd(x, w_bcdt, w_dw, w_hz, w_out, A, D):
+    return HsmssdFn.apply(x, w_bcdt, w_dw, w_hz, w_out, A, D)
+
+
+# ------------------------------------------------------------------------------------------ K3
+class DySampleFn(torch.autograd.Function):
+    """DySample 'lp' sampling stage given the 1x1 offset-conv output (DySample_md.py:49-68)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_out, init_pos, want_indices):
+        lib = _lib.load()
+        x, conv_out = _f32c(x, "x"), _f32c(conv_out, "offset conv output")
+        ipos = _f32c(init_pos, "init_pos").reshape(-1)
+        B, C, H, W = x.shape
+        if conv_out.shape != (B, 32, H, W) or ipos.numel() != 32:
+            raise RuntimeError("DySample: expected scale=2, groups=4 (32 offset channels), got %s" % (tuple(conv_out.shape),))
+        y = torch.empty(B, C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        ix0 = iy0 = None
+        if want_indices:
+            ix0 = torch.empty(B * 4, 2 * H, 2 * W, device=x.device, dtype=torch.int32)
+            iy0 = torch.empty_like(ix0)
+        _lib.check(lib.kmu_dysample_lp_fwd(_ptr(x), _ptr(conv_out), _ptr(ipos), _ptr(y), _ptr(ix0), _ptr(iy0), B, C, H, W,
+                                           _stream()), "kmu_dysample_lp_fwd")
+        ctx.save_for_backward(x, conv_out, ipos)
+        if want_indices:
+            ctx.mark_non_differentiable(ix0, iy0)
+            return y, ix0, iy0
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        lib = _lib.load()
+        x, conv_out, ipos = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B, C, H, W = x.shape
+        dx = torch.zeros_like(x)
+        dconv = torch.empty_like(conv_out)
+        _lib.check(lib.kmu_dysample_lp_bwd(_ptr(x), _ptr(conv_out), _ptr(ipos), _ptr(dy), _ptr(dx), _ptr(dconv), B, C, H, W,
+                                           _stream()), "kmu_dysample_lp_bwd")
+        return dx, dconv, None, None
+
+
+def dysample_lp(x, conv_out, init_pos, return_indices=False):
+    return DySampleFn.apply(x, conv_out, init_pos, return_indices)
+
+
+# ------------------------------------------------------------------------------------------ K4
+class DeformConv2dFn(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 deformable conv (torchvision.ops.DeformConv2d semantics, DAGEM_md.py:98-101)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, weight, bias):
+        lib = _lib.load()
+        x, offset, weight = _f32c(x, "x"), _f32c(offset, "offset"), _f32c(weight, "weight")
+        bias = _f32c(bias, "bias") if bias is not None else None
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        if tuple(weight.shape[1:]) != (Cin, 3, 3) or offset.shape != (B, 18, H, W):
+            raise RuntimeError("DeformConv2d: only 3x3/stride1/pad1/one offset group is built (weight %s, offset %s)"
+                               % (tuple(weight.shape), tuple(offset.shape)))
+        y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(lib.kmu_deform_conv2d_fwd(_ptr(x), _ptr(offset), _ptr(weight), _ptr(bias), _ptr(y), B, Cin, Cout, H, W,
+                                             _stream()), "kmu_deform_conv2d_fwd")
+        ctx.save_for_backward(x, offset, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, offset, weight = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dx, dw = torch.zeros_like(x), torch.zeros_like(weight)
+        db = torch.zeros(Cout, device=x.device, dtype=torch.float32)
+        doff = torch.empty_like(offset)
+        _lib.check(lib.kmu_deform_conv2d_bwd(_ptr(x), _ptr(offset), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dw),
+                                             _ptr(db), B, Cin, Cout, H, W, _stream()), "kmu_deform_conv2d_bwd")
+        return dx, doff, dw, (db if ctx.has_bias else None)
+
+
+def deform_conv2d(x, offset, weight, bias=None):
+    return DeformConv2dFn.apply(x, offset, weight, bias)

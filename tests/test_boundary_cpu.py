@@ -1,0 +1,78 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol the header
+declares (no compute calls -- there is no GPU here), the nn.Module surface reproduces the
+reference's state_dict manifest, and the hot path refuses to run without the HIP kernels."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def _lib():
+    import km_unet_amd  # noqa: F401
+    from km_unet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("kmu_build", os.path.join(ROOT, "km-unet_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    return _lib
+
+
+def test_header_symbols_exported():
+    _l = _lib()
+    lib = _l.load()
+    header = open(os.path.join(ROOT, "include", "kmunet_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(kmu_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_l.SIGNATURES), declared ^ set(_l.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.kmu_version() == 1
+    # size queries are pure host arithmetic and may be called without a GPU
+    assert lib.kmu_kan_pack_fwd_elems(16, 16) == 4 * 81 * 1 * 64
+    assert lib.kmu_kan_pack_bwd_elems(64, 32) == 8 * 81 * 4 * 64
+    assert lib.kmu_hsmssd_state_elems(2, 16, 64) == 2 * (128 + 4 * 16 * 64)
+
+
+@pytest.mark.parametrize("fname,variant,nc", [("manifest_sh_nc20.txt", "SH", 20), ("manifest_laps_nc3.txt", "LAPS", 3)])
+def test_product_state_dict_matches_reference_manifest(fname, variant, nc):
+    import km_unet_amd
+    want = sorted(tuple(l.split()) for l in open(os.path.join(GOLDEN, fname)).read().splitlines())
+    sd = km_unet_amd.KM_UNetV3(num_classes=nc, variant=variant).state_dict()
+    got = sorted((k, "x".join(map(str, v.shape)) or "scalar", str(v.dtype).replace("torch.", "")) for k, v in sd.items())
+    assert got == want
+    if variant == "SH":
+        assert len(got) == 920
+
+
+def test_product_and_oracle_exchange_state_dicts():
+    import km_unet_amd
+    from oracle.model import KM_UNetV3 as Oracle, fill_parameters
+    p = km_unet_amd.KM_UNetV3(num_classes=5)
+    o = fill_parameters(Oracle(num_classes=5), 1)
+    p.load_state_dict(o.state_dict(), strict=True)
+    o.load_state_dict(p.state_dict(), strict=True)
+
+
+def test_no_cpu_fallback():
+    import km_unet_amd
+    m = km_unet_amd.KM_UNetV3(num_classes=5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 5, 32, 32))
+    with pytest.raises(NotImplementedError):
+        km_unet_amd.KANConv2d(4, 4, 5, padding=2)
+    with pytest.raises(NotImplementedError):
+        km_unet_amd.DySample(64, scale=4)
+
+
+def test_kan_init_matches_reference_distribution():
+    """reset_parameters(): spline coefficients are a least-squares fit of +-0.01 noise => small."""
+    import km_unet_amd
+    k = km_unet_amd.KANLinear(36, 8)
+    assert k.spline_weight.abs().max() < 0.2 and torch.isfinite(k.spline_weight).all()
+    assert k.grid.shape == (36, 12) and torch.allclose(k.grid[0, 3], torch.tensor(-1.0))

@@ -1,0 +1,261 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP kernels, called through the C ABI, against
+(a) the golden vectors the reference produced and (b) the CPU oracle on seeded inputs.
+
+Tolerance: TOL = 1e-3 relative to the reference tensor's max magnitude -- the north_star's
+"within 1e-3 rel fp32" (all kernels compute in fp32; observed errors are ~1e-6..1e-5 and printed).
+DySample gather indices are integer work: bit-exact.
+"""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+DEV = "cuda"
+
+
+def _ops():
+    import km_unet_amd
+    return km_unet_amd.ops
+
+
+def _report(name, **errs):
+    print("  [%s] " % name + "  ".join("%s=%.2e" % kv for kv in errs.items()))
+    for k, v in errs.items():
+        assert v < TOL, (name, k, v)
+
+
+# ------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("name", ["k1_s0", "k1_s1", "k1_oos", "k1_border", "k1_wide"])
+def test_k1_golden(name):
+    g = load_golden(name)
+    ops = _ops()
+    x = g["x"].to(DEV).requires_grad_(True)
+    p = [g[k].to(DEV).requires_grad_(True) for k in ("base_weight", "spline_weight", "spline_scaler")]
+    y = ops.kan_conv2d(x, g["grid"].to(DEV), *p)
+    y.backward(g["gy"].to(DEV))
+    _report(name, y=rel_err(y, g["y"]), dx=rel_err(x.grad, g["dx"]), dbw=rel_err(p[0].grad, g["d_base_weight"]),
+            dsw=rel_err(p[1].grad, g["d_spline_weight"]), dsc=rel_err(p[2].grad, g["d_spline_scaler"]))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 16, 64, 64), (2, 16, 32, 32, 32), (2, 32, 64, 16, 16),
+                                             (2, 64, 32, 16, 16), (1, 16, 16, 128, 128), (1, 8, 24, 10, 13)])
+def test_k1_vs_oracle(B, Cin, Cout, H, W):
+    from oracle import kan as ok
+    ops = _ops()
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = (torch.randn(B, Cin, H, W, generator=gen) * 1.2).requires_grad_(True)
+    bw = (torch.randn(Cout, Cin * 9, generator=gen) * 0.1).requires_grad_(True)
+    sw = (torch.randn(Cout, Cin * 9, 8, generator=gen) * 0.1).requires_grad_(True)
+    sc = (torch.randn(Cout, Cin * 9, generator=gen) * 0.5).requires_grad_(True)
+    res = torch.randn(B, Cout, H, W, generator=gen).requires_grad_(True)
+    gy = torch.randn(B, Cout, H, W, generator=gen)
+    grid = ok.make_grid(Cin * 9)
+    yo = torch.relu(res + ok.kan_conv2d(x, grid, bw, sw, sc))
+    yo.backward(gy)
+    d = [t.detach().to(DEV).requires_grad_(True) for t in (x, bw, sw, sc, res)]
+    y = ops.kan_conv2d(d[0], grid.to(DEV), d[1], d[2], d[3], residual=d[4], relu=True)
+    y.backward(gy.to(DEV))
+    _report("k1 %s" % ((B, Cin, Cout, H, W),), y=rel_err(y, yo), dx=rel_err(d[0].grad, x.grad),
+            dbw=rel_err(d[1].grad, bw.grad), dsw=rel_err(d[2].grad, sw.grad), dsc=rel_err(d[3].grad, sc.grad),
+            dres=rel_err(d[4].grad, res.grad))
+
+
+def test_k1_full_size_properties():
+    """BASELINE size (B=8, 16->16 @128x128): size-independent properties instead of the (slow) oracle.
+    (1) linearity in the base weights, (2) zero spline+base weights give zero, (3) translation of the
+    batch axis: each sample is independent."""
+    ops = _ops()
+    from oracle import kan as ok
+    gen = torch.Generator().manual_seed(7)
+    B, C, H = 8, 16, 128
+    x = torch.randn(B, C, H, H, generator=gen).to(DEV)
+    grid = ok.make_grid(C * 9).to(DEV)
+    bw1, bw2 = (torch.randn(C, C * 9, generator=gen).to(DEV) * 0.1 for _ in range(2))
+    sw = (torch.randn(C, C * 9, 8, generator=gen) * 0.1).to(DEV)
+    sc = torch.randn(C, C * 9, generator=gen).to(DEV)
+    zsw = torch.zeros_like(sw)
+    y1 = ops.kan_conv2d(x, grid, bw1, zsw, sc)
+    y2 = ops.kan_conv2d(x, grid, bw2, zsw, sc)
+    y12 = ops.kan_conv2d(x, grid, bw1 + bw2, zsw, sc)
+    assert rel_err(y12, y1 + y2) < 1e-5
+    assert ops.kan_conv2d(x, grid, torch.zeros_like(bw1), zsw, sc).abs().max().item() == 0.0
+    ya = ops.kan_conv2d(x, grid, bw1, sw, sc)
+    yb = ops.kan_conv2d(x[3:5].contiguous(), grid, bw1, sw, sc)
+    assert torch.equal(ya[3:5], yb)
+
+
+# ------------------------------------------------------------------------------------------ K2
+@pytest.mark.parametrize("name", ["k2_c16", "k2_c32", "k2_c64"])
+def test_k2_golden_forward(name):
+    g = load_golden(name)
+    ops = _ops()
+    xn = ops.layernorm1d(g["x0"].to(DEV), g["ln_weight"].to(DEV), g["ln_bias"].to(DEV))
+    y, h = ops.hsmssd(g["xn"].to(DEV), *[g[k].to(DEV) for k in ("w_bcdt", "w_dw", "w_hz", "w_out", "A", "D")])
+    _report(name, ln=rel_err(xn, g["xn"]), y=rel_err(y, g["y"]), h=rel_err(h, g["h"]))
+
+
+@pytest.mark.parametrize("name", ["k2_c16", "k2_c32", "k2_c64"])
+def test_k2_golden_backward(name):
+    g = load_golden(name)
+    ops = _ops()
+    x0 = g["x0"].to(DEV).requires_grad_(True)
+    names = ("w_bcdt", "w_dw", "w_hz", "w_out", "A", "D")
+    p = {k: g[k].to(DEV).requires_grad_(True) for k in names + ("ln_weight", "ln_bias")}
+    xn = ops.layernorm1d(x0, p["ln_weight"], p["ln_bias"])
+    y, h = ops.hsmssd(xn, *[p[k] for k in names])
+    ((y * g["gy"].to(DEV)).sum() + (h * g["gh"].to(DEV)).sum()).backward()
+    errs = {"dx0": rel_err(x0.grad, g["d_x0"])}
+    for k in ("w_bcdt", "w_dw", "w_hz", "w_out", "D", "ln_weight", "ln_bias"):
+        errs["d_" + k] = rel_err(p[k].grad, g["d_" + k])
+    _report(name, **errs)
+    assert p["A"].grad.abs().max().item() == 0.0        # exact: A is a no-op parameter
+
+
+@pytest.mark.parametrize("B,C,Hs", [(2, 16, 32), (1, 16, 128), (2, 32, 64), (2, 64, 32), (1, 32, 20), (3, 64, 12)])
+def test_k2_vs_oracle(B, C, Hs):
+    from oracle import hsmssd as oh
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C * 100 + Hs)
+    N, L = 64, Hs * Hs
+    x = torch.randn(B, C, L, generator=gen).requires_grad_(True)
+    w = {"w_bcdt": torch.randn(3 * N, C, 1, generator=gen) / C ** 0.5, "w_dw": torch.randn(3 * N, 1, 3, 3, generator=gen) * 0.4,
+         "w_hz": torch.randn(2 * C, C, 1, generator=gen) / C ** 0.5, "w_out": torch.randn(C, C, 1, generator=gen) / C ** 0.5,
+         "A": torch.rand(N, generator=gen) * 15 + 1, "D": torch.ones(1) + 0.3}
+    w = {k: v.requires_grad_(True) for k, v in w.items()}
+    gy, gh = torch.randn(B, C, Hs, Hs, generator=gen), torch.randn(B, C, N, generator=gen) * 0.1
+    yo, ho = oh.hsmssd(x, *w.values(), state_dim=N)
+    ((yo * gy).sum() + (ho * gh).sum()).backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    wd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in w.items()}
+    y, h = ops.hsmssd(xd, *wd.values())
+    errs = {"y": rel_err(y, yo), "h": rel_err(h, ho)}
+    ((y * gy.to(DEV)).sum() + (h * gh.to(DEV)).sum()).backward()
+    errs["dx"] = rel_err(xd.grad, x.grad)
+    for k in ("w_bcdt", "w_dw", "w_hz", "w_out", "D"):
+        errs["d_" + k] = rel_err(wd[k].grad, w[k].grad)
+    _report("k2 %s" % ((B, C, Hs),), **errs)
+
+
+def test_k2_softmax_stability_and_shift_invariance():
+    """Property at full size (B=8, C=16, 128x128): adding a constant to the dt rows' bias-like shift
+    (a large A) must not change y (online-softmax rescale path with big magnitudes)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(3)
+    B, C, Hs, N = 8, 16, 128, 64
+    x = torch.randn(B, C, Hs * Hs, generator=gen).to(DEV)
+    w_bcdt = (torch.randn(3 * N, C, 1, generator=gen) * 2.0).to(DEV)      # large dt => sharp softmax
+    w_dw = torch.randn(3 * N, 1, 3, 3, generator=gen).to(DEV)
+    w_hz = (torch.randn(2 * C, C, 1, generator=gen) / 4).to(DEV)
+    w_out = (torch.randn(C, C, 1, generator=gen) / 4).to(DEV)
+    D = torch.ones(1, device=DEV)
+    y1, h1 = ops.hsmssd(x, w_bcdt, w_dw, w_hz, w_out, torch.zeros(N, device=DEV), D)
+    y2, h2 = ops.hsmssd(x, w_bcdt, w_dw, w_hz, w_out, torch.full((N,), 1e4, device=DEV), D)
+    assert torch.isfinite(y1).all() and torch.equal(y1, y2) and torch.equal(h1, h2)
+    # batch independence
+    y3, _ = ops.hsmssd(x[2:3].contiguous(), w_bcdt, w_dw, w_hz, w_out, torch.zeros(N, device=DEV), D)
+    assert rel_err(y3, y1[2:3]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ K3
+@pytest.mark.parametrize("name", ["k3_default", "k3_large", "k3_b2", "k3_16"])
+def test_k3_golden(name):
+    g = load_golden(name)
+    ops = _ops()
+    import torch.nn.functional as F
+    x = g["x"].to(DEV).requires_grad_(True)
+    w = g["w_off"].to(DEV).requires_grad_(True)
+    b = g["b_off"].to(DEV).requires_grad_(True)
+    y = ops.dysample_lp(x, F.conv2d(x, w, b), g["init_pos"].to(DEV))
+    y.backward(g["gy"].to(DEV))
+    _report(name, y=rel_err(y, g["y"]), dx=rel_err(x.grad, g["dx"]), dw=rel_err(w.grad, g["d_w_off"]),
+            db=rel_err(b.grad, g["d_b_off"]))
+    # index generation, bit exact: feed the SAME conv output to the kernel and to the oracle
+    from oracle import dysample as od
+    conv_cpu = F.conv2d(g["x"], g["w_off"], g["b_off"])
+    off = conv_cpu * 0.25 + g["init_pos"]
+    ix_o, iy_o, _, _ = od.sample_indices(od.normalized_coords(off), g["x"].shape[2], g["x"].shape[3])
+    _, ix, iy = ops.dysample_lp(g["x"].to(DEV), conv_cpu.to(DEV), g["init_pos"].to(DEV), return_indices=True)
+    assert torch.equal(ix.cpu(), ix_o) and torch.equal(iy.cpu(), iy_o)
+    assert torch.equal(ix_o, g["ix0"]) and torch.equal(iy_o, g["iy0"])
+
+
+@pytest.mark.parametrize("B,H,W,std", [(8, 64, 64, 0.5), (2, 60, 60, 1.0), (1, 15, 30, 2.0), (4, 16, 16, 0.001)])
+def test_k3_indices_bit_exact_large(B, H, W, std):
+    """Index generation at full size incl. non power-of-two extents (config 5: 60/120/240)."""
+    from oracle import dysample as od
+    ops = _ops()
+    gen = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(B, 64, H, W, generator=gen)
+    conv = torch.randn(B, 32, H, W, generator=gen) * std
+    ipos = od.init_pos()
+    ix_o, iy_o, _, _ = od.sample_indices(od.normalized_coords(conv * 0.25 + ipos), H, W)
+    y, ix, iy = ops.dysample_lp(x.to(DEV), conv.to(DEV), ipos.to(DEV), return_indices=True)
+    assert torch.equal(ix.cpu(), ix_o) and torch.equal(iy.cpu(), iy_o)
+    assert int(ix.min()) >= 0 and int(ix.max()) <= W - 1 and int(iy.min()) >= 0 and int(iy.max()) <= H - 1
+    import torch.nn.functional as F
+    yo = F.grid_sample(x.reshape(B * 4, 16, H, W), od.normalized_coords(conv * 0.25 + ipos), mode="bilinear",
+                       align_corners=False, padding_mode="border").view(B, 64, 2 * H, 2 * W)
+    assert rel_err(y, yo) < TOL
+
+
+# ------------------------------------------------------------------------------------------ K4
+@pytest.mark.parametrize("B,C,Co,H,W,std", [(2, 64, 64, 16, 16, 0.5), (1, 8, 12, 7, 9, 2.0), (2, 16, 16, 8, 8, 5.0)])
+def test_k4_vs_oracle(B, C, Co, H, W, std):
+    from oracle import deform as odf
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=gen).requires_grad_(True)
+    off = (torch.randn(B, 18, H, W, generator=gen) * std).requires_grad_(True)
+    wt = (torch.randn(Co, C, 3, 3, generator=gen) / (3 * C ** 0.5)).requires_grad_(True)
+    bs = torch.randn(Co, generator=gen).requires_grad_(True)
+    gy = torch.randn(B, Co, H, W, generator=gen)
+    yo = odf.deform_conv2d(x, off, wt, bs)
+    yo.backward(gy)
+    d = [t.detach().to(DEV).requires_grad_(True) for t in (x, off, wt, bs)]
+    y = ops.deform_conv2d(*d)
+    y.backward(gy.to(DEV))
+    _report("k4 %s" % ((B, C, Co, H, W),), y=rel_err(y, yo), dx=rel_err(d[0].grad, x.grad), doff=rel_err(d[1].grad, off.grad),
+            dw=rel_err(d[2].grad, wt.grad), db=rel_err(d[3].grad, bs.grad))
+
+
+# ------------------------------------------------------------------------------------------ blocks
+@pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
+def test_evim_block_golden(name, train):
+    import km_unet_amd
+    from oracle.model import fill_parameters
+    g = load_golden(name)
+    m = fill_parameters(km_unet_amd.EfficientViMBlock(16, state_dim=64), 7 + int(train)).to(DEV)
+    m.train(train)
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    y.backward(g["gy"].to(DEV))
+    _report(name, y=rel_err(y, g["y"]), dx=rel_err(x.grad, g["dx"]))
+
+
+def test_iwp_golden():
+    import km_unet_amd
+    from oracle.model import fill_parameters
+    g = load_golden("iwp_c16")
+    m = fill_parameters(km_unet_amd.IntelligentWaveletPoolingModule(16), 3).to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    y.backward(g["gy"].to(DEV))
+    _report("iwp", y=rel_err(y, g["y"]), dx=rel_err(x.grad, g["dx"]))
+
+
+def test_error_paths():
+    """The C ABI rejects bad arguments with a message instead of launching."""
+    import km_unet_amd
+    from km_unet_amd import _lib
+    lib = _lib.load()
+    assert lib.kmu_kan_conv2d_fwd(None, None, None, None, None, 1, 1, 1, 1, 1, 0, None) == -1
+    assert b"null" in lib.kmu_last_error()
+    with pytest.raises(RuntimeError):
+        km_unet_amd.ops.hsmssd(torch.randn(1, 24, 16, device=DEV), torch.randn(192, 24, 1, device=DEV),
+                               torch.randn(192, 1, 3, 3, device=DEV), torch.randn(48, 24, 1, device=DEV),
+                               torch.randn(24, 24, 1, device=DEV), torch.ones(64, device=DEV), torch.ones(1, device=DEV))
+    with pytest.raises(RuntimeError):
+        km_unet_amd.ops.kan_conv2d(torch.randn(1, 4, 4, 4), torch.zeros(36, 12), torch.zeros(4, 36), torch.zeros(4, 36, 8),
+                                   torch.zeros(4, 36))          # CPU tensor: no fallback
