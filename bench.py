@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- training frames/s of KM_UNetV3 (SH) on synthetic [B,T,1,128,128] sequences.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference loop body (train_shanghai.py:163-181): slice 5 input / T-5 target frames,
+forward, loss, backward, gradient all-reduce (RCCL, N > 1), AdamW step.  Workload = BASELINE.json
+configs[1]: KM_UNetV3_SH, B=8 per GPU, T=10 (=> num_classes 5), 128x128; weak scaling (global batch
+8*N).  Arithmetic is fp32 end to end (>= the reference's fp16 autocast; the CPU fp32 path is the
+parity oracle), data is synthetic (torch.rand, seed 0), weights are random-init of that architecture.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant hand-written kernel of the step, timed per launch with HIP events on the
+                  launch stream during extra instrumented steps of the same workload;
+  cpu_baseline -- the CPU oracle ("port" of the reference op sequence) timed on this host's cores
+                  on a bounded sample (B=2, same T/H/W), N=1 only;
+  kernels      -- per-entry-point totals of those instrumented steps (ms per step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
+
+
+def kernel_model(name, shape):
+    """Algorithmic work of one launch (DESIGN.md 'Kernels'): (bound, flops, bytes)."""
+    if name.startswith("kan_conv2d"):
+        B, Cin, Cout, H, W = shape
+        flops = 2.0 * B * H * W * (81 * Cin) * Cout           # implicit GEMM, K = 9 taps x 9 basis x Cin
+        byts = 4.0 * B * H * W * (Cin + Cout) + 4.0 * 81 * Cin * Cout
+        if name.endswith("bwd_input"):
+            byts = 4.0 * B * H * W * (2 * Cin + Cout) + 4.0 * 81 * Cin * Cout
+        return "mfma", flops, byts
+    if name.startswith("hsmssd"):
+        B, C, Hs = shape
+        L, N = Hs * Hs, 64
+        flops = B * L * (2.0 * 3 * N * C + 2.0 * 9 * 3 * N + 4.0 * C * N)
+        byts = 4.0 * B * C * L * 2
+        if name.endswith("bwd"):
+            flops, byts = 3.0 * flops, 4.0 * B * C * L * 3
+        return "hbm", flops, byts
+    if name.startswith("dysample"):
+        B, C, H, W = shape
+        byts = 4.0 * B * C * H * W * 5 + 4.0 * B * 32 * H * W
+        if name.endswith("bwd"):
+            byts *= 2
+        return "hbm", 12.0 * B * C * 4 * H * W, byts
+    return "hbm", 0.0, 0.0
+
+
+def cpu_baseline(T, H, steps=3):
+    """CPU oracle (oracle/model.py = the reference's op sequence) fwd + MSE + bwd + AdamW, B=2."""
+    from oracle.model import KM_UNetV3 as Oracle
+    torch.manual_seed(0)
+    B = 2
+    m = Oracle(num_classes=T - 5).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.05)
+    data = torch.rand(B, T, 1, H, H)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        d = data.squeeze(2)
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(m(d[:, :5]), d[:, 5:])
+        loss.backward()
+        opt.step()
+        if i:
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": B * T / t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle KM_UNetV3 train step (fwd+MSE+bwd+AdamW) at B=%d,T=%d,%dx%d fp32, median of %d steps after 1 warm-up, %.2f s/step"
+                      % (B, T, H, H, steps, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run eagerly instead of replaying a captured hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import km_unet_amd
+    from km_unet_amd import ops
+    from km_unet_amd.train import TrainStep
+
+    B, T, H = args.batch, args.frames, args.size
+    torch.manual_seed(0)
+    model = km_unet_amd.KM_UNetV3(num_classes=T - 5).to(dev).train()
+    torch.manual_seed(1234 + rank)            # per-rank data shard and DropPath stream
+    data = torch.rand(B, T, 1, H, H, device=dev)
+    step = TrainStep(model, data)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step(data)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(data)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    final_loss = loss.item()
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {"metric": "train frames/sec (BxT) KM-UNetV3_SH 128x128 T=10", "value": world * B * T / (dt / args.steps),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "KM_UNetV3_SH(num_classes=%d) train step (fwd + MSE + bwd + grad all-reduce + AdamW), "
+                                      "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, B, T, H, H),
+                          "global_batch": world * B, "frames_per_sample": T, "parallelism": "dp%d" % world},
+               "loss": final_loss}
+
+    # ---- roofline leg: extra instrumented steps, HIP events around every C-ABI launch ----------
+    if rank == 0:
+        nprof = 3
+        ops.profile_begin()
+        for _ in range(nprof):
+            step(data)
+        prof = ops.profile_end()
+        table = {}
+        for (name, shape), ms_list in prof.items():
+            bound, flops, byts = kernel_model(name, shape)
+            per = sum(ms_list) / len(ms_list)
+            table["%s%s" % (name, list(shape))] = {
+                "launches_per_step": len(ms_list) / nprof, "avg_ms": per, "ms_per_step": sum(ms_list) / nprof,
+                "bound": bound, "GB/s": byts / per / 1e6 if per else 0.0, "TFLOP/s": flops / per / 1e9 if per else 0.0}
+        dom = max(table, key=lambda k: table[k]["ms_per_step"])
+        d = table[dom]
+        (name, shape) = next(k for k in prof if "%s%s" % (k[0], list(k[1])) == dom)
+        bound, flops, byts = kernel_model(name, shape)
+        if bound == "mfma":
+            roof = {"bound": "mfma", "achieved": d["TFLOP/s"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": d["TFLOP/s"] / PEAK_F32_MFMA_TFLOPS}
+        else:
+            roof = {"bound": "hbm", "achieved": d["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["GB/s"] / PEAK_HBM_GBS}
+        roof.update({"traffic": None, "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_flops": flops,
+                     "algorithmic_bytes": byts, "hbm_GBps_on_algorithmic_bytes": d["GB/s"]})
+        out["roofline"] = roof
+        out["kernels"] = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
+                          sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        out["hip_kernels_ms_per_step"] = sum(v["ms_per_step"] for v in table.values())
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, H)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

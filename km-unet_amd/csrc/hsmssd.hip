@@ -450,8 +450,6 @@ __global__ __launch_bounds__(256) void ln1d_bwd_kernel(const float* __restrict__
     }
 }
 
-#include "hsmssd_bwd.inc"
-
 // ---------------------------------------------------------------------------------------------
 template <int C>
 size_t lds_pass1() {
@@ -491,6 +489,8 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
     hipLaunchKernelGGL(hsm_fwd_pass2<C>, dim3(T, B), dim3(256), l2, st, x, w_bcdt, w_dw, state, y, Hs, tilesX);
     return kmu::launch_status("hsmssd_fwd pass2");
 }
+
+#include "hsmssd_bwd.inc"
 
 }  // namespace
 
@@ -538,11 +538,35 @@ extern "C" int kmu_layernorm1d_bwd(const float* x, const float* weight, const fl
 }
 
 // ---- backward entry points (kernels in hsmssd_bwd.inc) -------------------------------------------
-extern "C" size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs) { (void)B; (void)C; (void)N; (void)Hs; return 0; }
-extern "C" int kmu_hsmssd_bwd_partials(int B, int C, int Hs) { (void)B; (void)C; (void)Hs; return 0; }
-extern "C" int kmu_hsmssd_bwd(const float*, const float*, const float*, const float*, const float*, const float*,
-                              const float*, const float*, const float*, float*, float*, float*, float*, float*, float*,
-                              void*, size_t, int, int, int, int, kmu_stream_t) {
-    kmu::set_error("hsmssd_bwd: not built yet");
-    return KMU_ERR_ARG;
+extern "C" size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs) {
+    int tx;
+    const int TA = tiles_for(C, Hs, &tx);
+    return ((size_t)B * TA * C * N + (size_t)B * C * N + (size_t)B * N) * sizeof(float);
+}
+extern "C" int kmu_hsmssd_bwd_partials(int B, int C, int Hs) {
+    int tx;
+    return B * tilesB_for(C, Hs, &tx);
+}
+extern "C" int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
+                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
+                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
+                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
+                              int Hs, kmu_stream_t stream) {
+    KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial &&
+                    d_w_hz_partial && d_w_out_partial && d_D_partial && ws,
+                "hsmssd_bwd: null pointer");
+    KMU_REQUIRE(N == NS, "hsmssd_bwd: state_dim=%d unsupported (kernels are built for 64)", N);
+    KMU_REQUIRE(C == 16 || C == 32 || C == 64, "hsmssd_bwd: C=%d unsupported (16/32/64)", C);
+    KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0, "hsmssd_bwd: bad dims");
+    KMU_REQUIRE(ws_bytes >= kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs), "hsmssd_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* w = (float*)ws;
+    if (C == 16)
+        return bwd_impl<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                            d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, st);
+    if (C == 32)
+        return bwd_impl<32>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                            d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, st);
+    return bwd_impl<64>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                        d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, st);
 }

@@ -1,0 +1,70 @@
+"""Batch-sharded data parallelism: one process per GPU, one flat fp32 gradient bucket, one
+sum-all-reduce per step (RCCL over xGMI when the backend is "nccl"; gloo on CPU for tests).
+
+The reference has no distributed code at all; this is the only exchange step the
+path has: replicas hold the full 6.9 MB of weights, rank r trains on its own batch shard, and
+gradients are averaged.  Design notes (MI355X):
+  * the gradients of all parameters that can ever receive one live in ONE contiguous buffer
+    (`param.grad` are views into it), so the collective is a single ~5 MB message -- latency-bound on
+    xGMI, where one large ring/tree call beats many small ones; no per-step flatten/unflatten copies;
+  * 50 parameter tensors (26 % of the weights: branches.plain, attn, dt_proj -- KM_UNetV3_SH.py:27-34,
+    50-54,163) never get a gradient; they are discovered once with a dry backward and left out of the
+    bucket (their .grad stays None, AdamW skips them);
+  * BatchNorm uses per-replica batch statistics, exactly like the reference on one GPU (no SyncBN,
+    DAGEM_md.py:8-12 ignores its sync_bn flag); buffers are broadcast from rank 0 at start-up.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    def __init__(self, params):
+        self.params = [p for p in params]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def numel(self):
+        return self.flat.numel()
+
+
+def live_parameters(model, example_input, loss_fn=None):
+    """Parameters that receive a gradient from one dry forward/backward (static for this model)."""
+    was_training = model.training
+    out = model(example_input)
+    (loss_fn(out) if loss_fn else out.float().mean()).backward()
+    live = [p for p in model.parameters() if p.grad is not None]
+    for p in model.parameters():
+        p.grad = None
+    model.train(was_training)
+    return live
+
+
+class DataParallel:
+    """Minimal DDP: broadcast parameters/buffers from rank 0, average gradients after backward."""
+
+    def __init__(self, model, live_params, process_group=None):
+        self.model = model
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if self.world > 1:
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, src=0, group=process_group)
+        self.bucket = FlatGradBucket(live_params)
+
+    def zero_grad(self):
+        self.bucket.zero_()
+
+    def all_reduce_grads(self):
+        if self.world == 1:
+            return
+        dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
+        self.bucket.flat.div_(self.world)

@@ -13,6 +13,34 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+_PROF = None
+
+
+def profile_begin():
+    global _PROF
+    _PROF = {}
+
+
+def profile_end():
+    """-> {(entry point, shape): [ms per launch]} ; synchronises."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    return {k: [s.elapsed_time(e) for s, e in v] for k, v in (prof or {}).items()}
+
+
+def _call(key, fn, *args):
+    if _PROF is None:
+        return fn(*args)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn(*args)
+    e.record()
+    _PROF.setdefault(key, []).append((s, e))
+    return rc
+
+
 def _f32c(t, name):
     if not t.is_cuda:
         raise RuntimeError("%s: %s is on %s; the KM-UNet hot path only runs as HIP kernels on an MI355X "
@@ -65,8 +93,8 @@ class KanConv2dFn(torch.autograd.Function):
         y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
         if residual is not None:
             residual = _f32c(residual, "residual")
-        _lib.check(lib.kmu_kan_conv2d_fwd(_ptr(x), _ptr(knots), _ptr(wp_f), _ptr(residual), _ptr(y), B, Cin, Cout, H, W,
-                                          1 if relu else 0, st), "kmu_kan_conv2d_fwd")
+        _lib.check(_call(("kan_conv2d_fwd", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_fwd, _ptr(x), _ptr(knots), _ptr(wp_f),
+                         _ptr(residual), _ptr(y), B, Cin, Cout, H, W, 1 if relu else 0, st), "kmu_kan_conv2d_fwd")
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, knots, spline_w, scaler, wp_b, y if relu else None)
@@ -85,17 +113,17 @@ class KanConv2dFn(torch.autograd.Function):
         dx = d_bw = d_sw = d_sc = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(lib.kmu_kan_conv2d_bwd_input(_ptr(x), _ptr(dy), _ptr(knots), _ptr(wp_b), _ptr(dx), B, Cin, Cout, H, W, st),
-                       "kmu_kan_conv2d_bwd_input")
+            _lib.check(_call(("kan_conv2d_bwd_input", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_input, _ptr(x), _ptr(dy),
+                             _ptr(knots), _ptr(wp_b), _ptr(dx), B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_input")
         if any(ctx.needs_input_grad[2:5]):
             nbytes = lib.kmu_kan_bwd_ws_bytes(B, Cin, Cout, H, W)
             ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
             d_bw = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
             d_sw = torch.empty(Cout, Cin * 9, 8, device=x.device, dtype=torch.float32)
             d_sc = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
-            _lib.check(lib.kmu_kan_conv2d_bwd_weights(_ptr(x), _ptr(dy), _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw),
-                                                      _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes, B, Cin, Cout, H, W, st),
-                       "kmu_kan_conv2d_bwd_weights")
+            _lib.check(_call(("kan_conv2d_bwd_weights", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights, _ptr(x), _ptr(dy),
+                             _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
+                             B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights")
         return dx, None, d_bw, d_sw, d_sc, (dy if ctx.has_res else None), None
 
 
@@ -160,8 +188,9 @@ class HsmssdFn(torch.autograd.Function):
         state = torch.empty(lib.kmu_hsmssd_state_elems(B, C, N), device=dev, dtype=torch.float32)
         nbytes = lib.kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs)
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
-        _lib.check(lib.kmu_hsmssd_fwd(_ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(y), _ptr(h),
-                                      _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, _stream()), "kmu_hsmssd_fwd")
+        _lib.check(_call(("hsmssd_fwd", (B, C, Hs)), lib.kmu_hsmssd_fwd, _ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
+                         _ptr(w_out), _ptr(D), _ptr(y), _ptr(h), _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, _stream()),
+                   "kmu_hsmssd_fwd")
         ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
         ctx.dims = (B, C, N, Hs)
         ctx.A_shape = A.shape
@@ -184,9 +213,9 @@ class HsmssdFn(torch.autograd.Function):
         p_D = torch.empty(B, device=dev, dtype=torch.float32)
         nbytes = lib.kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
-        _lib.check(lib.kmu_hsmssd_bwd(_ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz), _ptr(w_out), _ptr(D),
-                                      _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz), _ptr(p_out), _ptr(p_D),
-                                      _ptr(ws), nbytes, B, C, N, Hs, _stream()), "kmu_hsmssd_bwd")
+        _lib.check(_call(("hsmssd_bwd", (B, C, Hs)), lib.kmu_hsmssd_bwd, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
+                         _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
+                         _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, _stream()), "kmu_hsmssd_bwd")
         # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd
         # returns ~1e-7 rounding noise here)
         return (dx, p_bcdt.sum(0).view(3 * N, C, 1), p_dw.sum(0).view(3 * N, 1, 3, 3), p_hz.sum(0).view(2 * C, C, 1),
@@ -214,8 +243,8 @@ class DySampleFn(torch.autograd.Function):
         if want_indices:
             ix0 = torch.empty(B * 4, 2 * H, 2 * W, device=x.device, dtype=torch.int32)
             iy0 = torch.empty_like(ix0)
-        _lib.check(lib.kmu_dysample_lp_fwd(_ptr(x), _ptr(conv_out), _ptr(ipos), _ptr(y), _ptr(ix0), _ptr(iy0), B, C, H, W,
-                                           _stream()), "kmu_dysample_lp_fwd")
+        _lib.check(_call(("dysample_lp_fwd", (B, C, H, W)), lib.kmu_dysample_lp_fwd, _ptr(x), _ptr(conv_out), _ptr(ipos), _ptr(y),
+                         _ptr(ix0), _ptr(iy0), B, C, H, W, _stream()), "kmu_dysample_lp_fwd")
         ctx.save_for_backward(x, conv_out, ipos)
         if want_indices:
             ctx.mark_non_differentiable(ix0, iy0)
@@ -230,8 +259,8 @@ class DySampleFn(torch.autograd.Function):
         B, C, H, W = x.shape
         dx = torch.zeros_like(x)
         dconv = torch.empty_like(conv_out)
-        _lib.check(lib.kmu_dysample_lp_bwd(_ptr(x), _ptr(conv_out), _ptr(ipos), _ptr(dy), _ptr(dx), _ptr(dconv), B, C, H, W,
-                                           _stream()), "kmu_dysample_lp_bwd")
+        _lib.check(_call(("dysample_lp_bwd", (B, C, H, W)), lib.kmu_dysample_lp_bwd, _ptr(x), _ptr(conv_out), _ptr(ipos), _ptr(dy),
+                         _ptr(dx), _ptr(dconv), B, C, H, W, _stream()), "kmu_dysample_lp_bwd")
         return dx, dconv, None, None
 
 

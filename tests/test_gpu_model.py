@@ -1,0 +1,74 @@
+"""GPU parity of the whole KM_UNetV3 graph (HIP hot blocks + PyTorch-ROCm glue) against the golden
+vectors the reference produced on CPU fp32 (tests/golden/model_*.npz), forward and backward.
+Tolerance 1e-3 relative (north_star); whole-model weight gradients are compared per tensor."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _build(variant, nc, train):
+    import km_unet_amd
+    from oracle.model import fill_parameters
+    m = fill_parameters(km_unet_amd.KM_UNetV3(num_classes=nc, variant=variant), 1).cuda()
+    m.train(train)
+    for sub in m.modules():
+        if hasattr(sub, "drop_prob"):
+            sub.drop_prob = 0.0          # DropPath is third-party RNG, disabled in the fixtures too
+    return m
+
+
+@pytest.mark.parametrize("name,variant,nc,train", [("model_sh_eval", "SH", 5, False), ("model_sh_train", "SH", 5, True),
+                                                    ("model_laps_eval", "LAPS", 3, False)])
+def test_whole_model_golden(name, variant, nc, train):
+    g = load_golden(name)
+    m = _build(variant, nc, train)
+    x = g["x"].cuda().requires_grad_(True)
+    y = m(x)
+    loss = torch.nn.functional.mse_loss(y, g["target"].cuda())
+    loss.backward()
+    e_y, e_dx = rel_err(y, g["y"]), rel_err(x.grad, g["dx"])
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(grads) == list(g["grad_keys"])
+    assert sum(1 for _, p in m.named_parameters() if p.grad is None) == int(g["n_no_grad"])
+    worst = ("", 0.0)
+    for k in g:
+        if k.startswith("g__") and not k.endswith("__A"):
+            e = rel_err(grads[k[3:].replace("__", ".")], g[k])
+            worst = max(worst, (k, e), key=lambda t: t[1])
+    bad = 0
+    for k, a in zip(g["grad_keys"], g["grad_abs"]):
+        if k.endswith(".A"):
+            continue
+        got = grads[k].double().abs().sum().item()
+        if abs(got - a) > 2e-3 * max(a, 1e-7) + 1e-9:
+            bad += 1
+            print("   grad |sum| mismatch", k, got, a)
+    print("  [%s] y=%.2e dx=%.2e loss=%.3e worst_grad=%s %.2e bad=%d" % (name, e_y, e_dx, abs(loss.item() - g["loss"].item()),
+                                                                         worst[0][-40:], worst[1], bad))
+    assert e_y < TOL and e_dx < TOL and worst[1] < TOL and bad == 0
+
+
+def test_model_matches_oracle_at_128():
+    """[2,5,128,128] (config 1 shape): product on GPU vs the CPU oracle with identical weights."""
+    import km_unet_amd
+    from oracle.model import KM_UNetV3 as Oracle, fill_parameters
+    o = fill_parameters(Oracle(num_classes=5), 3).eval()
+    m = km_unet_amd.KM_UNetV3(num_classes=5)
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.cuda().eval()
+    x = torch.rand(2, 5, 128, 128, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        yo = o(x)
+        y = m(x.cuda())
+    e = rel_err(y, yo)
+    # CSI "parity" (SURVEY 8f-2): contingency scores of both outputs against the same target agree
+    from oracle.csi import scores
+    tgt = torch.rand(2, 5, 128, 128, generator=torch.Generator().manual_seed(12)).numpy()
+    so, sp = scores(yo.numpy(), tgt), scores(y.cpu().numpy(), tgt)
+    dcsi = max(abs(so[t]["csi"] - sp[t]["csi"]) for t in so if so[t]["csi"] == so[t]["csi"])
+    print("  [model128] y=%.2e  max|dCSI|=%.2e" % (e, dcsi))
+    assert e < TOL and dcsi < 1e-3
