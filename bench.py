@@ -65,6 +65,9 @@ def cpu_baseline(T, H, steps=3):
     """CPU oracle (oracle/model.py = the reference's op sequence) fwd + MSE + bwd + AdamW, B=2."""
     from oracle.model import KM_UNetV3 as Oracle
     torch.manual_seed(0)
+    # one GPU's host share on the box is 16 cores; more threads only add oversubscription on these
+    # small tensors (measured: 128 threads = 14.6 s/step, slower than 8 threads in the build container)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     B = 2
     m = Oracle(num_classes=T - 5).train()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.05)

@@ -59,8 +59,25 @@ def build(force=False, verbose=False):
             rebuilt = True
         objs.append(o)
     if rebuilt or not os.path.exists(LIB):
+        _screen_isa(hipcc)
         subprocess.check_call([hipcc, "-shared", "-o", LIB] + objs + ["--offload-arch=" + ARCH, "-fno-gpu-rdc"])
     return LIB
+
+
+def _screen_isa(hipcc):
+    """Refuse to link if any MFMA has partially overlapping vdst / srcC register ranges (a hipcc 7.2
+    codegen hazard that silently corrupts accumulators -- tools/check_mfma_overlap.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kmu_isa_check", os.path.join(HERE, "..", "tools", "check_mfma_overlap.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    for src, extra in SOURCES:
+        path = os.path.join(CSRC, src)
+        if "mfma" not in open(path).read() and not any("mfma" in open(h).read() for h in [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]):
+            continue
+        hits = chk.scan(chk.disassemble(path, hipcc, extra))
+        if hits:
+            raise RuntimeError("MFMA with partially overlapping vdst/srcC in %s: %s" % (src, hits[:3]))
 
 
 if __name__ == "__main__":

@@ -76,3 +76,26 @@ def test_kan_init_matches_reference_distribution():
     k = km_unet_amd.KANLinear(36, 8)
     assert k.spline_weight.abs().max() < 0.2 and torch.isfinite(k.spline_weight).all()
     assert k.grid.shape == (36, 12) and torch.allclose(k.grid[0, 3], torch.tensor(-1.0))
+
+
+def test_dropin_import_paths():
+    """`sys.path.insert(0, "km-unet_amd/dropin")` then the reference's own import lines work
+    (train_shanghai.py:7, KM_UNetV3_SH.py:6,13,16-18).  Run in a subprocess: the shim module names
+    collide with the real reference's when that is on sys.path (tests/golden/make_golden.py)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from KM_UNetV3_SH import KM_UNetV3\n"
+        "from KM_UNetV3_LAPS import KM_UNetV3 as L\n"
+        "from convKAN.KANConv2Dlayers import *\n"
+        "from vim_block_init.efficient_vim_init import EfficientViMBlock, HSMSSD\n"
+        "from WPL.iwp import IntelligentWaveletPoolingModule\n"
+        "from DAGEM_md import DAGEM\n"
+        "from DySample_md import DySample\n"
+        "m = KM_UNetV3(num_classes=20); assert len(m.state_dict()) == 920\n"
+        "assert 'bridge_attention.deform_conv.weight' not in L(num_classes=3).state_dict()\n"
+        "assert KANConv2d(4, 4, 3, padding=1).kanlayer.grid.shape == (36, 12)\n"
+        "print('ok')\n") % os.path.join(ROOT, "km-unet_amd", "dropin")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

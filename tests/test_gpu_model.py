@@ -44,7 +44,8 @@ def test_whole_model_golden(name, variant, nc, train):
         if k.endswith(".A"):
             continue
         got = grads[k].double().abs().sum().item()
-        if abs(got - a) > 2e-3 * max(a, 1e-7) + 1e-9:
+        # |grad| L1 mass per tensor within 2e-3 (plus an absolute floor for tensors whose gradient is ~0)
+        if abs(got - a) > 2e-3 * a + 1e-6:
             bad += 1
             print("   grad |sum| mismatch", k, got, a)
     print("  [%s] y=%.2e dx=%.2e loss=%.3e worst_grad=%s %.2e bad=%d" % (name, e_y, e_dx, abs(loss.item() - g["loss"].item()),
