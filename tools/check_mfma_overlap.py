@@ -11,10 +11,30 @@ import sys
 PAT = re.compile(r"v_mfma_\S+\s+([av])\[(\d+):(\d+)\],\s*\S+,\s*\S+,\s*([av])\[(\d+):(\d+)\]")
 
 
+WR = re.compile(r"^(v_accvgpr_write_b32|v_accvgpr_mov_b32|v_mov_b32_e32|v_mov_b32)\s+([av])(\d+),")
+WINDOW = 8   # wait states hipcc itself leaves (s_nop 7) between a 16x16x4 f32 MFMA and a VALU write to its SrcC
+
+
 def scan(asm_text):
     hits, kernel = [], "?"
-    for ln, line in enumerate(asm_text.splitlines(), 1):
+    lines = asm_text.splitlines()
+    pending = []   # (file, lo, hi, remaining, text) SrcC ranges of recently issued MFMAs
+    for ln, line in enumerate(lines, 1):
         s = line.strip()
+        if not s or s.startswith(";") or s.startswith("."):
+            if s.startswith(".type") and "@function" in s:
+                pass
+            else:
+                continue
+        w = WR.match(s)
+        if w:
+            f, r = w.group(2), int(w.group(3))
+            for (pf, lo, hi, _, text, dst) in pending:
+                if pf == f and lo <= r <= hi and not (dst[0] == f and dst[1] <= r <= dst[2]):
+                    hits.append((kernel, ln, "WAR on SrcC: '%s' right after '%s'" % (s, text)))
+        n = re.match(r"s_nop\s+(\d+)", s)
+        states = int(n.group(1)) + 1 if n else 1
+        pending = [(a, b, c, d - states, e, g) for (a, b, c, d, e, g) in pending if d > states]
         if s.startswith(".type") and "@function" in s:
             kernel = s.split()[1].split(",")[0]
         m = PAT.search(s)
@@ -22,6 +42,7 @@ def scan(asm_text):
             fd, d0, d1, fc, c0, c1 = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4), int(m.group(5)), int(m.group(6))
             if fd == fc and (d0, d1) != (c0, c1) and not (d1 < c0 or c1 < d0):
                 hits.append((kernel, ln, s))
+            pending.append((fc, c0, c1, WINDOW, s, (fd, d0, d1)))
     return hits
 
 
