@@ -3,9 +3,17 @@
 The directory name carries a hyphen; import it as ``km_unet_amd`` (root-level km_unet_amd.py
 registers this directory under that module name).
 """
-from . import _lib, ops  # noqa: F401
-from .model import KM_UNetV3  # noqa: F401
-from .nn import (DAGEM, DeformConv2d, DySample, EfficientViMBlock, HSMSSD, IntelligentWaveletPoolingModule,  # noqa: F401
+import os as _os
+
+# Numerics policy for the PyTorch-ROCm glue: MIOpen's Winograd solvers (miopenSp3AsmConv f2x3/f3x2) are
+# picked or not depending on its timing-based Find step, and when picked they move whole-model fp32
+# gradients by 1.5e-4 .. 1.4e-3 relative (measured on MI355X; 5e-6 without them) -- above the 1e-3
+# parity budget against the reference's CPU fp32 path.  Direct / implicit-GEMM solvers only.
+_os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+
+from . import _lib, ops  # noqa: E402,F401
+from .model import KM_UNetV3  # noqa: E402,F401
+from .nn import (DAGEM,  # noqa: E402 DeformConv2d, DySample, EfficientViMBlock, HSMSSD, IntelligentWaveletPoolingModule,  # noqa: F401
                  KANConv2d, KANLinear, LayerNorm1D)
 
 __all__ = ["KM_UNetV3", "KANConv2d", "KANLinear", "HSMSSD", "LayerNorm1D", "EfficientViMBlock", "DySample", "DAGEM",

@@ -2,6 +2,8 @@ import os
 import sys
 import warnings
 
+os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")   # same numerics policy as km-unet_amd/__init__.py
+
 import numpy as np
 import pytest
 import torch
