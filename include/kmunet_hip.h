@@ -107,11 +107,13 @@ int kmu_hsmssd_fwd(const float* x, const float* w_bcdt, const float* w_dw, const
 size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs);
 /* number of per-workgroup partial slabs written for d_w_bcdt / d_w_dw (caller sums over dim 0) */
 int kmu_hsmssd_bwd_partials(int B, int C, int Hs);
+/* number of partial rows G written for d_w_hz / d_w_out / d_D by the gate stage (B x state-column groups) */
+int kmu_hsmssd_gate_partials(int B);
 int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh /*may be NULL*/, const float* w_bcdt,
                    const float* w_dw, const float* w_hz, const float* w_out, const float* D, const float* state,
                    float* dx, float* d_w_bcdt_partial /*[P,3N,C]*/, float* d_w_dw_partial /*[P,3N,9]*/,
-                   float* d_w_hz_partial /*[B,2C,C]*/, float* d_w_out_partial /*[B,C,C]*/,
-                   float* d_D_partial /*[B]*/, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,
+                   float* d_w_hz_partial /*[G,2C,C]*/, float* d_w_out_partial /*[G,C,C]*/,
+                   float* d_D_partial /*[G]*/, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,
                    kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -143,6 +145,21 @@ int kmu_deform_conv2d_fwd(const float* x, const float* offset, const float* weig
 int kmu_deform_conv2d_bwd(const float* x, const float* offset, const float* weight, const float* dy, float* dx,
                           float* d_offset, float* d_weight, float* d_bias, int B, int Cin, int Cout, int H, int W,
                           kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Depthwise 3x3 / stride 1 / pad 1 convolution: EfficientViMBlock.dwconv1/dwconv2
+ * (vim_block_init/efficient_vim_init.py:74-75 -> ConvLayer2D, vim_utils_init.py:62-89, groups=dim, no bias)
+ * and DirectionAttention.conv (KM_UNetV3_SH.py:222, groups=dim, bias).
+ * weight [C,1,3,3] (= [C,9]); bias [C] or NULL.  Weight/bias gradients are per-block partials
+ * [P,C,9] / [P,C] with P = kmu_dwconv3x3_partials(B); d_bias_partial may be NULL.
+ * ------------------------------------------------------------------------------------ */
+int kmu_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C, int H, int W,
+                      kmu_stream_t stream);
+int kmu_dwconv3x3_bwd_data(const float* dy, const float* weight, float* dx, int B, int C, int H, int W,
+                           kmu_stream_t stream);
+int kmu_dwconv3x3_partials(int B);
+int kmu_dwconv3x3_bwd_weight(const float* x, const float* dy, float* d_weight_partial, float* d_bias_partial, int B,
+                             int C, int H, int W, kmu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,8 @@ _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
 
 from . import _lib, ops  # noqa: E402,F401
 from .model import KM_UNetV3  # noqa: E402,F401
-from .nn import (DAGEM,  # noqa: E402 DeformConv2d, DySample, EfficientViMBlock, HSMSSD, IntelligentWaveletPoolingModule,  # noqa: F401
-                 KANConv2d, KANLinear, LayerNorm1D)
+from .nn import DAGEM, DeformConv2d, DySample, EfficientViMBlock, HSMSSD  # noqa: E402,F401
+from .nn import IntelligentWaveletPoolingModule, KANConv2d, KANLinear, LayerNorm1D  # noqa: E402,F401
 
 __all__ = ["KM_UNetV3", "KANConv2d", "KANLinear", "HSMSSD", "LayerNorm1D", "EfficientViMBlock", "DySample", "DAGEM",
            "DeformConv2d", "IntelligentWaveletPoolingModule", "ops"]

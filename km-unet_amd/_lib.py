@@ -32,11 +32,16 @@ SIGNATURES = {
     "kmu_hsmssd_fwd": (_I, [_P] * 10 + [_Z] + [_I] * 4 + [_P]),
     "kmu_hsmssd_bwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_hsmssd_bwd_partials": (_I, [_I] * 3),
+    "kmu_hsmssd_gate_partials": (_I, [_I]),
     "kmu_hsmssd_bwd": (_I, [_P] * 16 + [_Z] + [_I] * 4 + [_P]),
     "kmu_dysample_lp_fwd": (_I, [_P] * 6 + [_I] * 4 + [_P]),
     "kmu_dysample_lp_bwd": (_I, [_P] * 6 + [_I] * 4 + [_P]),
     "kmu_deform_conv2d_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "kmu_deform_conv2d_bwd": (_I, [_P] * 8 + [_I] * 5 + [_P]),
+    "kmu_dwconv3x3_fwd": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "kmu_dwconv3x3_bwd_data": (_I, [_P] * 3 + [_I] * 4 + [_P]),
+    "kmu_dwconv3x3_partials": (_I, [_I]),
+    "kmu_dwconv3x3_bwd_weight": (_I, [_P] * 4 + [_I] * 4 + [_P]),
 }
 
 _lock = threading.Lock()

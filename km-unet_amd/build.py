@@ -22,6 +22,7 @@ SOURCES = [
     ("hsmssd.hip", []),
     ("dysample.hip", ["-ffp-contract=off"]),
     ("deform_conv2d.hip", []),
+    ("dwconv3x3.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

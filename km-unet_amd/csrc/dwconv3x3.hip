@@ -1,0 +1,152 @@
+// Depthwise 3x3 / stride 1 / pad 1 convolution for gfx950 (forward, input gradient, weight gradient).
+//
+// Used 45x per forward by the reference graph: EfficientViMBlock.dwconv1/dwconv2
+// (vim_block_init/efficient_vim_init.py:74-75,85,93 -> ConvLayer2D, vim_utils_init.py:62-89, groups=dim,
+// bias-free) and DirectionAttention.conv (KM_UNetV3_SH.py:222,263, groups=dim, with bias).  MIOpen serves
+// this shape with its naive fallback kernel (~50 us for [8,16,128,128]); it is a pure HBM-bound stencil:
+// algorithmic traffic = read x once + write y once.
+//   forward / input gradient: one thread per 4 consecutive output pixels (16-B store), 3 rows x 6 taps read
+//       straight from global (neighbouring threads share lines through L1/L2); the input gradient is the same
+//       stencil with the taps flipped.
+//   weight gradient: grid (C, B, row-splits); 9 tap sums + the bias sum per thread, wave shuffle + LDS block
+//       reduce, per-block partials (deterministic; the caller sums the small partial tensor).
+#include "common.h"
+
+using kmu::floatx4;
+
+namespace {
+
+constexpr int WSPLIT = 4;  // row splits per (b, c) plane in the weight-gradient kernel
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int C,
+                                                        int H, int W, int flip, size_t total) {
+    const int W4 = (W + 3) >> 2;
+    const bool vec_ok = (W & 3) == 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int x0 = (int)(t % W4) * 4;
+        size_t r = t / W4;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C);
+        const float* plane = in + r * (size_t)H * W;  // r == b*C + c
+        float wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = w[c * 9 + (flip ? 8 - k : k)];
+        const float b0 = bias ? bias[c] : 0.f;
+        float acc[4] = {b0, b0, b0, b0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float* row = plane + (size_t)yy * W;
+            float v[6];
+            if (vec_ok) {
+                const floatx4 m = *reinterpret_cast<const floatx4*>(row + x0);
+                v[1] = m[0], v[2] = m[1], v[3] = m[2], v[4] = m[3];
+                v[0] = x0 > 0 ? row[x0 - 1] : 0.f;
+                v[5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int xx = x0 - 1 + k;
+                    v[k] = (xx >= 0 && xx < W) ? row[xx] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[q] += wv[dy * 3 + dx] * v[q + dx];
+        }
+        float* dst = out + (r * H + y) * (size_t)W + x0;
+        if (vec_ok) {
+            *reinterpret_cast<floatx4*>(dst) = floatx4{acc[0], acc[1], acc[2], acc[3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (x0 + q < W) dst[q] = acc[q];
+        }
+    }
+}
+
+// dw[c][tap] partial = sum over this block's rows of dy[p] * x[p + tap - centre] ; db partial = sum dy
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ dy,
+                                                                   float* __restrict__ dw_part,
+                                                                   float* __restrict__ db_part, int C, int H, int W) {
+    __shared__ float red[4][10];
+    const int c = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int rows = (H + WSPLIT - 1) / WSPLIT, y0 = sp * rows, y1 = min(H, y0 + rows);
+    const float* xp = x + ((size_t)b * C + c) * H * W;
+    const float* gp = dy + ((size_t)b * C + c) * H * W;
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    const int npix = max(0, y1 - y0) * W;
+    for (int p = threadIdx.x; p < npix; p += 256) {
+        const int y = y0 + p / W, xx = p % W;
+        const float g = gp[(size_t)y * W + xx];
+        acc[9] += g;
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+            const int yy = y + dyy - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dxx = 0; dxx < 3; ++dxx) {
+                const int xc = xx + dxx - 1;
+                if (xc >= 0 && xc < W) acc[dyy * 3 + dxx] += g * xp[(size_t)yy * W + xc];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float s = kmu::wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const size_t prow = (size_t)b * WSPLIT + sp;
+        if (threadIdx.x < 9)
+            dw_part[(prow * C + c) * 9 + threadIdx.x] = s;
+        else if (db_part)
+            db_part[prow * C + c] = s;
+    }
+}
+
+int launch_stencil(const float* in, const float* w, const float* bias, float* out, int B, int C, int H, int W, int flip,
+                   hipStream_t st, const char* what) {
+    const size_t total = (size_t)B * C * H * ((W + 3) / 4);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, out, C, H, W, flip, total);
+    return kmu::launch_status(what);
+}
+
+}  // namespace
+
+extern "C" int kmu_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C, int H,
+                                 int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && weight && y, "dwconv3x3_fwd: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_fwd: bad dims");
+    return launch_stencil(x, weight, bias, y, B, C, H, W, 0, (hipStream_t)stream, "dwconv3x3_fwd");
+}
+
+extern "C" int kmu_dwconv3x3_bwd_data(const float* dy, const float* weight, float* dx, int B, int C, int H, int W,
+                                      kmu_stream_t stream) {
+    KMU_REQUIRE(dy && weight && dx, "dwconv3x3_bwd_data: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_bwd_data: bad dims");
+    return launch_stencil(dy, weight, nullptr, dx, B, C, H, W, 1, (hipStream_t)stream, "dwconv3x3_bwd_data");
+}
+
+extern "C" int kmu_dwconv3x3_partials(int B) { return B * WSPLIT; }
+
+extern "C" int kmu_dwconv3x3_bwd_weight(const float* x, const float* dy, float* d_weight_partial,
+                                        float* d_bias_partial, int B, int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && dy && d_weight_partial, "dwconv3x3_bwd_weight: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "dwconv3x3_bwd_weight: bad dims");
+    hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(C, B, WSPLIT), dim3(256), 0, (hipStream_t)stream, x, dy,
+                       d_weight_partial, d_bias_partial, C, H, W);
+    return kmu::launch_status("dwconv3x3_bwd_weight");
+}

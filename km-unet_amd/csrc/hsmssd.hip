@@ -234,61 +234,67 @@ __host__ __device__ inline size_t state_stride(int C) { return (size_t)2 * NS + 
 
 __device__ __forceinline__ float silu(float z) { return z / (1.f + __expf(-z)); }
 
+constexpr int GN = 8;        // state columns per gate workgroup
+constexpr int NGRP = NS / GN;  // gate workgroups per batch element
+
+// All gate arithmetic is independent across the state index n (hz_proj / out_proj contract over channels), so
+// a batch element is split over NGRP workgroups of GN columns each: grid (B, NGRP).
 __global__ __launch_bounds__(256) void hsm_fwd_gate(const float* __restrict__ part_ms,
                                                     const float* __restrict__ part_acc,
                                                     const float* __restrict__ w_hz, const float* __restrict__ w_out,
                                                     const float* __restrict__ Dp, float* __restrict__ state,
                                                     float* __restrict__ h_out, int C, int T) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ms = smem;            // [64]
-    float* Ss = Ms + NS;         // [64]
-    float* hp = Ss + NS;         // [C][64]
-    float* hz = hp + C * NS;     // [2C][64]
-    float* gg = hz + 2 * C * NS; // [C][64]
-    const int tid = threadIdx.x, b = blockIdx.x;
+    float* Ms = smem;             // [GN]
+    float* Ss = Ms + GN;          // [GN]
+    float* hp = Ss + GN;          // [C][GN]
+    float* hz = hp + C * GN;      // [2C][GN]
+    float* gg = hz + 2 * C * GN;  // [C][GN]
+    const int tid = threadIdx.x, b = blockIdx.x, nb = blockIdx.y * GN;
     const float* pms = part_ms + (size_t)b * T * 2 * NS;
     const float* pac = part_acc + (size_t)b * T * NS * C;
     float* st = state + (size_t)b * state_stride(C);
-    if (tid < NS) {
+    if (tid < GN) {
+        const int n = nb + tid;
         float M = -INFINITY;
-        for (int t = 0; t < T; ++t) M = fmaxf(M, pms[(size_t)t * 2 * NS + tid]);
+        for (int t = 0; t < T; ++t) M = fmaxf(M, pms[(size_t)t * 2 * NS + n]);
         float S = 0.f;
-        for (int t = 0; t < T; ++t) S += pms[(size_t)t * 2 * NS + NS + tid] * __expf(pms[(size_t)t * 2 * NS + tid] - M);
+        for (int t = 0; t < T; ++t) S += pms[(size_t)t * 2 * NS + NS + n] * __expf(pms[(size_t)t * 2 * NS + n] - M);
         Ms[tid] = M;
         Ss[tid] = S;
-        st[tid] = M;
-        st[NS + tid] = S;
+        st[n] = M;
+        st[NS + n] = S;
     }
     __syncthreads();
-    for (int e = tid; e < C * NS; e += 256) {  // e = n*C + c in the partial layout
-        const int n = e / C, c = e - n * C;
+    for (int e = tid; e < C * GN; e += 256) {  // e = nl*C + c (the partial layout is [n][C])
+        const int nl = e / C, c = e - nl * C, n = nb + nl;
         float a = 0.f;
-        for (int t = 0; t < T; ++t) a += pac[(size_t)t * NS * C + e] * __expf(pms[(size_t)t * 2 * NS + n] - Ms[n]);
-        a /= Ss[n];
-        hp[c * NS + n] = a;
+        for (int t = 0; t < T; ++t) a += pac[(size_t)t * NS * C + n * C + c] * __expf(pms[(size_t)t * 2 * NS + n] - Ms[nl]);
+        a /= Ss[nl];
+        hp[c * GN + nl] = a;
         st[2 * NS + c * NS + n] = a;
     }
     __syncthreads();
-    for (int e = tid; e < 2 * C * NS; e += 256) {  // hz[k][n] = sum_c W_hz[k][c] hpre[c][n]   (:52)
-        const int k = e / NS, n = e - k * NS;
+    for (int e = tid; e < 2 * C * GN; e += 256) {  // hz[k][n] = sum_c W_hz[k][c] hpre[c][n]   (:52)
+        const int k = e / GN, nl = e - k * GN;
         float a = 0.f;
-        for (int c = 0; c < C; ++c) a += w_hz[k * C + c] * hp[c * NS + n];
+        for (int c = 0; c < C; ++c) a += w_hz[k * C + c] * hp[c * GN + nl];
         hz[e] = a;
-        st[2 * NS + C * NS + e] = a;
+        st[2 * NS + C * NS + k * NS + nb + nl] = a;
     }
     __syncthreads();
     const float Dv = Dp[0];
-    for (int e = tid; e < C * NS; e += 256) {  // g = h1*SiLU(z) + h1*D   (:55)
-        const float h1 = hz[e], z = hz[C * NS + e];
+    for (int e = tid; e < C * GN; e += 256) {  // g = h1*SiLU(z) + h1*D   (:55)
+        const float h1 = hz[e], z = hz[C * GN + e];
         gg[e] = h1 * silu(z) + h1 * Dv;
     }
     __syncthreads();
-    for (int e = tid; e < C * NS; e += 256) {  // h2[c'][n] = sum_c W_out[c'][c] g[c][n]
-        const int co = e / NS, n = e - co * NS;
+    for (int e = tid; e < C * GN; e += 256) {  // h2[c'][n] = sum_c W_out[c'][c] g[c][n]
+        const int co = e / GN, nl = e - co * GN;
         float a = 0.f;
-        for (int c = 0; c < C; ++c) a += w_out[co * C + c] * gg[c * NS + n];
-        st[2 * NS + 3 * C * NS + e] = a;
-        h_out[(size_t)b * C * NS + e] = a;
+        for (int c = 0; c < C; ++c) a += w_out[co * C + c] * gg[c * GN + nl];
+        st[2 * NS + 3 * C * NS + co * NS + nb + nl] = a;
+        h_out[(size_t)b * C * NS + co * NS + nb + nl] = a;
     }
 }
 
@@ -481,9 +487,8 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
     hipLaunchKernelGGL(hsm_fwd_pass1<C>, dim3(T, B), dim3(256), l1, st, x, w_bcdt, w_dw, part_ms, part_acc, Hs, tilesX);
     int rc = kmu::launch_status("hsmssd_fwd pass1");
     if (rc) return rc;
-    const size_t lg = ((size_t)2 * NS + 4 * C * NS) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)hsm_fwd_gate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg);
-    hipLaunchKernelGGL(hsm_fwd_gate, dim3(B), dim3(256), lg, st, part_ms, part_acc, w_hz, w_out, D, state, h, C, T);
+    const size_t lg = ((size_t)2 * GN + 4 * C * GN) * sizeof(float);
+    hipLaunchKernelGGL(hsm_fwd_gate, dim3(B, NGRP), dim3(256), lg, st, part_ms, part_acc, w_hz, w_out, D, state, h, C, T);
     rc = kmu::launch_status("hsmssd_fwd gate");
     if (rc) return rc;
     hipLaunchKernelGGL(hsm_fwd_pass2<C>, dim3(T, B), dim3(256), l2, st, x, w_bcdt, w_dw, state, y, Hs, tilesX);
@@ -543,6 +548,7 @@ extern "C" size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs) {
     const int TA = tiles_for(C, Hs, &tx);
     return ((size_t)B * TA * C * N + (size_t)B * C * N + (size_t)B * N) * sizeof(float);
 }
+extern "C" int kmu_hsmssd_gate_partials(int B) { return B * NGRP; }
 extern "C" int kmu_hsmssd_bwd_partials(int B, int C, int Hs) {
     int tx;
     return B * tilesB_for(C, Hs, &tx);

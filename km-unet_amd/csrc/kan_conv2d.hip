@@ -468,6 +468,19 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_kernel(const float* __rest
     }
 }
 
+// stage 1 of the slab reduction: every 256-thread block sums up to RG splits of one (ct,ot,f) slab row
+// (fully coalesced 1-KiB reads); stage 2 (below) sums the <= ceil(S/RG) group partials and unpacks.
+constexpr int RG = 16;
+__global__ __launch_bounds__(256) void kan_bwd_weight_reduce1_kernel(const float* __restrict__ slab,
+                                                                     float* __restrict__ part, int S, int SG) {
+    const int f = blockIdx.x % 81, pair = blockIdx.x / 81, sg = blockIdx.y;
+    const float* src = slab + (((size_t)pair * S + (size_t)sg * RG) * 81 + f) * 256 + threadIdx.x;
+    const int n = min(RG, S - sg * RG);
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += src[(size_t)i * 81 * 256];
+    part[(((size_t)pair * SG + sg) * 81 + f) * 256 + threadIdx.x] = acc;
+}
+
 // sum slabs over splits and unpack dW' into the three parameter gradients (KANlayers.py:644-660 autograd)
 __global__ void kan_bwd_weight_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ sw,
                                              const float* __restrict__ sc, float* __restrict__ d_bw,
@@ -597,7 +610,8 @@ extern "C" int kmu_kan_conv2d_bwd_input(const float* x, const float* dy, const f
 
 extern "C" size_t kmu_kan_bwd_ws_bytes(int B, int Cin, int Cout, int H, int W) {
     const int CT = kmu::cdiv(Cin, 16), OT = kmu::cdiv(Cout, 16);
-    return (size_t)CT * OT * bwd_weight_splits(B, Cin, Cout, H, W) * 81 * 256 * sizeof(float);
+    const int S = bwd_weight_splits(B, Cin, Cout, H, W);
+    return (size_t)CT * OT * ((size_t)S + kmu::cdiv(S, RG)) * 81 * 256 * sizeof(float);
 }
 
 extern "C" int kmu_kan_conv2d_bwd_weights(const float* x, const float* dy, const float* knots,
@@ -621,9 +635,14 @@ extern "C" int kmu_kan_conv2d_bwd_weights(const float* x, const float* dy, const
                        Cout, H, W, OT, S, tilesX, tilesY);
     int rc = kmu::launch_status("kan_conv2d_bwd_weights");
     if (rc) return rc;
+    const int SG = kmu::cdiv(S, RG);
+    float* part = (float*)ws + (size_t)CT * OT * S * 81 * 256;
+    hipLaunchKernelGGL(kan_bwd_weight_reduce1_kernel, dim3(CT * OT * 81, SG), dim3(256), 0, st, (const float*)ws, part, S, SG);
+    rc = kmu::launch_status("kan_conv2d_bwd_weights_reduce1");
+    if (rc) return rc;
     const size_t total = (size_t)CT * OT * 9 * 256;
     hipLaunchKernelGGL(kan_bwd_weight_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       (const float*)ws, spline_weight, spline_scaler, d_base_weight, d_spline_weight,
-                       d_spline_scaler, Cin, Cout, OT, CT, S);
+                       (const float*)part, spline_weight, spline_scaler, d_base_weight, d_spline_weight,
+                       d_spline_scaler, Cin, Cout, OT, CT, SG);
     return kmu::launch_status("kan_conv2d_bwd_weights_reduce");
 }

@@ -14,7 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d
+from . import ops
+from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, conv1x1
 
 
 class DropPath(nn.Module):
@@ -53,7 +54,8 @@ class StableHybridKANConv(nn.Module):
 
     def forward(self, x):
         x = self.pre_norm(x)
-        return self.kanconv2d[0](x, residual=self.residual(x), relu=True)
+        res = x if isinstance(self.residual, nn.Identity) else conv1x1(x, self.residual)
+        return self.kanconv2d[0](x, residual=res, relu=True)
 
 
 class DirectionAttention(nn.Module):
@@ -69,8 +71,8 @@ class DirectionAttention(nn.Module):
     def forward(self, x):
         b, c = x.shape[:2]
         gate = self.fc(x.mean(dim=(2, 3)))
-        q, k, v = self.qkv(x).chunk(3, dim=1)
-        return self.conv(torch.sigmoid(q * k) * v) * gate.view(b, c, 1, 1)
+        q, k, v = conv1x1(x, self.qkv).chunk(3, dim=1)
+        return ops.dwconv3x3(torch.sigmoid(q * k) * v, self.conv.weight, self.conv.bias) * gate.view(b, c, 1, 1)
 
 
 class DirectionViM(nn.Module):
@@ -86,7 +88,8 @@ class DirectionViM(nn.Module):
         self.attn = DirectionAttention(dim, mode)
 
     def forward(self, x):
-        return self.attn(self.vit_mamba(self.proj(x)))
+        x = conv1x1(x, self.proj) if self.mode == "channel" else self.proj(x)
+        return self.attn(self.vit_mamba(x))
 
 
 class TripleNorm(nn.Module):
@@ -123,7 +126,8 @@ class EnhancedViMBlock(nn.Module):
         feats = [self.height_block(x), self.width_block(x), self.channel_block(x)]
         g = self.fusion_gate(torch.cat(feats, dim=1))
         x = x + self.drop_path(g[:, 0:1] * feats[0] + g[:, 1:2] * feats[1] + g[:, 2:3] * feats[2])
-        return x + self.drop_path(self.ffn(self.norm(x)))
+        f = conv1x1(F.gelu(conv1x1(self.norm(x), self.ffn[0])), self.ffn[2])
+        return x + self.drop_path(f)
 
 
 class ChannelAttention(nn.Module):

@@ -12,6 +12,21 @@ import torch.nn.functional as F
 from . import ops
 
 
+def conv1x1(x, conv):
+    """1x1 convolution of an nn.Conv2d's parameters as ONE strided-batched GEMM  W[Co,Ci] @ x[b][Ci, H*W].
+    (MIOpen serves NCHW 1x1 convs with im2col + batched transposes around a GEMM: 3-4 launches.)"""
+    b, ci, h, w = x.shape
+    co = conv.weight.shape[0]
+    y = torch.bmm(conv.weight.view(1, co, ci).expand(b, co, ci), x.reshape(b, ci, h * w))
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, co, 1)
+    return y.view(b, co, h, w)
+
+
+def _is_pointwise(c):
+    return c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and c.groups == 1
+
+
 # ------------------------------------------------------------------ convKAN (K1)
 class KANLinear(nn.Module):
     """Parameter container compatible with convKAN/KANlayers.py:505-575.
@@ -126,7 +141,14 @@ class ConvLayer2D(nn.Module):
             nn.init.constant_(self.norm.bias, 0)
 
     def forward(self, x):
-        x = self.conv(x)
+        c = self.conv
+        if c.groups == c.in_channels == c.out_channels and c.kernel_size == (3, 3) and c.stride == (1, 1) \
+                and c.padding == (1, 1) and c.dilation == (1, 1):
+            x = ops.dwconv3x3(x, c.weight, c.bias)          # HIP stencil instead of MIOpen's naive fallback
+        elif _is_pointwise(c):
+            x = conv1x1(x, c)
+        else:
+            x = c(x)
         if self.norm:
             x = self.norm(x)
         return self.act(x) if self.act else x
@@ -289,5 +311,5 @@ class IntelligentWaveletPoolingModule(nn.Module):
     def forward(self, x):
         ll, lh, hl, hh = self.dwt(x)
         high = torch.cat([lh, hl, hh], dim=1)
-        high = high * self.softmax(self.high_freq_conv(high))
-        return self.fusion_conv(torch.cat([ll, high.mean(dim=1, keepdim=True)], dim=1))
+        high = high * self.softmax(conv1x1(high, self.high_freq_conv))
+        return conv1x1(torch.cat([ll, high.mean(dim=1, keepdim=True)], dim=1), self.fusion_conv)

@@ -208,9 +208,10 @@ class HsmssdFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         p_bcdt = torch.empty(P, 3 * N, C, device=dev, dtype=torch.float32)
         p_dw = torch.empty(P, 3 * N, 9, device=dev, dtype=torch.float32)
-        p_hz = torch.empty(B, 2 * C, C, device=dev, dtype=torch.float32)
-        p_out = torch.empty(B, C, C, device=dev, dtype=torch.float32)
-        p_D = torch.empty(B, device=dev, dtype=torch.float32)
+        G = lib.kmu_hsmssd_gate_partials(B)
+        p_hz = torch.empty(G, 2 * C, C, device=dev, dtype=torch.float32)
+        p_out = torch.empty(G, C, C, device=dev, dtype=torch.float32)
+        p_D = torch.empty(G, device=dev, dtype=torch.float32)
         nbytes = lib.kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
         _lib.check(_call(("hsmssd_bwd", (B, C, Hs)), lib.kmu_hsmssd_bwd, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
@@ -306,3 +307,50 @@ class DeformConv2dFn(torch.autograd.Function):
 
 def deform_conv2d(x, offset, weight, bias=None):
     return DeformConv2dFn.apply(x, offset, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------ depthwise 3x3
+class DwConv3x3Fn(torch.autograd.Function):
+    """Depthwise 3x3/s1/p1 conv (ConvLayer2D with groups=dim, vim_utils_init.py:62-89; DirectionAttention.conv,
+    KM_UNetV3_SH.py:222)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, w = _f32c(x, "x"), _f32c(weight, "weight")
+        b = _f32c(bias, "bias") if bias is not None else None
+        B, C, H, W = x.shape
+        if tuple(w.shape) != (C, 1, 3, 3):
+            raise RuntimeError("dwconv3x3: weight %s does not match a depthwise 3x3 conv over %d channels" % (tuple(w.shape), C))
+        y = torch.empty_like(x)
+        _lib.check(_call(("dwconv3x3_fwd", (B, C, H, W)), lib.kmu_dwconv3x3_fwd, _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, C, H, W,
+                         _stream()), "kmu_dwconv3x3_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B, C, H, W = x.shape
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(_call(("dwconv3x3_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_data, _ptr(dy), _ptr(w), _ptr(dx), B, C, H,
+                             W, st), "kmu_dwconv3x3_bwd_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            P = lib.kmu_dwconv3x3_partials(B)
+            dwp = torch.empty(P, C, 9, device=x.device, dtype=torch.float32)
+            dbp = torch.empty(P, C, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dy), _ptr(dwp),
+                             _ptr(dbp), B, C, H, W, st), "kmu_dwconv3x3_bwd_weight")
+            dw = dwp.sum(0).view(C, 1, 3, 3)
+            db = dbp.sum(0) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def dwconv3x3(x, weight, bias=None):
+    return DwConv3x3Fn.apply(x, weight, bias)

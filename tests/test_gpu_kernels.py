@@ -220,6 +220,28 @@ def test_k4_vs_oracle(B, C, Co, H, W, std):
             dw=rel_err(d[2].grad, wt.grad), db=rel_err(d[3].grad, bs.grad))
 
 
+# ------------------------------------------------------------------------------------------ depthwise 3x3
+@pytest.mark.parametrize("B,C,H,W,bias", [(2, 16, 32, 32, False), (8, 16, 128, 128, True), (3, 64, 7, 9, True), (1, 32, 4, 4, False)])
+def test_dwconv3x3_vs_torch_cpu(B, C, H, W, bias):
+    """ConvLayer2D(groups=dim) / DirectionAttention.conv: compare with F.conv2d(groups=C) on CPU fp32."""
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=gen).requires_grad_(True)
+    w = (torch.randn(C, 1, 3, 3, generator=gen) * 0.3).requires_grad_(True)
+    b = torch.randn(C, generator=gen).requires_grad_(True) if bias else None
+    gy = torch.randn(B, C, H, W, generator=gen)
+    yo = F.conv2d(x, w, b, padding=1, groups=C)
+    yo.backward(gy)
+    d = [t.detach().to(DEV).requires_grad_(True) if t is not None else None for t in (x, w, b)]
+    y = ops.dwconv3x3(*d)
+    y.backward(gy.to(DEV))
+    errs = {"y": rel_err(y, yo), "dx": rel_err(d[0].grad, x.grad), "dw": rel_err(d[1].grad, w.grad)}
+    if bias:
+        errs["db"] = rel_err(d[2].grad, b.grad)
+    _report("dwconv %s" % ((B, C, H, W),), **errs)
+
+
 # ------------------------------------------------------------------------------------------ blocks
 @pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
 def test_evim_block_golden(name, train):
