@@ -115,14 +115,15 @@ def main():
 
     import km_unet_amd
     from km_unet_amd import ops
-    from km_unet_amd.train import TrainStep
+    from km_unet_amd.train import GraphedTrainStep, TrainStep
 
     B, T, H = args.batch, args.frames, args.size
     torch.manual_seed(0)
     model = km_unet_amd.KM_UNetV3(num_classes=T - 5).to(dev).train()
     torch.manual_seed(1234 + rank)            # per-rank data shard and DropPath stream
     data = torch.rand(B, T, 1, H, H, device=dev)
-    step = TrainStep(model, data)
+    eager = TrainStep(model, data, capturable=not args.no_graph)
+    step = eager if args.no_graph else GraphedTrainStep(eager, data)
 
     def sync():
         if world > 1:
@@ -152,14 +153,14 @@ def main():
                "config": {"workload": "KM_UNetV3_SH(num_classes=%d) train step (fwd + MSE + bwd + grad all-reduce + AdamW), "
                                       "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, B, T, H, H),
                           "global_batch": world * B, "frames_per_sample": T, "parallelism": "dp%d" % world},
-               "loss": final_loss}
+               "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay"}
 
     # ---- roofline leg: extra instrumented steps, HIP events around every C-ABI launch ----------
     if rank == 0:
         nprof = 3
         ops.profile_begin()
         for _ in range(nprof):
-            step(data)
+            eager(data)                      # eager: HIP events bracket each launch on the launch stream
         prof = ops.profile_end()
         table = {}
         for (name, shape), ms_list in prof.items():

@@ -38,6 +38,17 @@ __device__ __forceinline__ float wave_max(float v) {
 
 }  // namespace kmu
 
+// Raise a kernel's dynamic-LDS limit once per call site / template instantiation (never during a later
+// stream capture: the first, un-captured warm-up call does it).
+#define KMU_MAX_LDS(kern, bytes)                                                                                   \
+    do {                                                                                                           \
+        static size_t kmu_lds_cfg_ = 48 * 1024;                                                                    \
+        if ((size_t)(bytes) > kmu_lds_cfg_) {                                                                      \
+            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            kmu_lds_cfg_ = (size_t)(bytes);                                                                        \
+        }                                                                                                          \
+    } while (0)
+
 #define KMU_REQUIRE(cond, ...)          \
     do {                                \
         if (!(cond)) {                  \

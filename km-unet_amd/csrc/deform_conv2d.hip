@@ -171,8 +171,7 @@ extern "C" int kmu_deform_conv2d_fwd(const float* x, const float* offset, const 
     KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "deform_conv2d_fwd: bad dims");
     const size_t lds = (size_t)Cin * 9 * PXB * sizeof(float);
     KMU_REQUIRE(lds <= 160 * 1024, "deform_conv2d_fwd: Cin=%d too large for the LDS column tile", Cin);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)deform_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    KMU_MAX_LDS(deform_fwd_kernel, lds);
     const int blocks = kmu::cdiv(B * H * W, PXB);
     hipLaunchKernelGGL(deform_fwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, offset, weight, bias, y,
                        B, Cin, Cout, H, W);
@@ -186,8 +185,7 @@ extern "C" int kmu_deform_conv2d_bwd(const float* x, const float* offset, const 
     KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "deform_conv2d_bwd: bad dims");
     const size_t lds = ((size_t)2 * Cin * 9 + Cout) * PXB * sizeof(float);
     KMU_REQUIRE(lds <= 160 * 1024, "deform_conv2d_bwd: channels too large for the LDS tiles");
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)deform_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    KMU_MAX_LDS(deform_bwd_kernel, lds);
     const int blocks = kmu::cdiv(B * H * W, PXB);
     hipLaunchKernelGGL(deform_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, offset, weight, dy, dx,
                        d_offset, d_weight, d_bias, B, Cin, Cout, H, W);

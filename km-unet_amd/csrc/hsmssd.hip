@@ -482,8 +482,8 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
     float* part_ms = ws;
     float* part_acc = ws + (size_t)B * T * 2 * NS;
     const size_t l1 = lds_pass1<C>(), l2 = lds_pass2<C>();
-    (void)hipFuncSetAttribute((const void*)hsm_fwd_pass1<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
-    (void)hipFuncSetAttribute((const void*)hsm_fwd_pass2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    KMU_MAX_LDS(hsm_fwd_pass1<C>, l1);
+    KMU_MAX_LDS(hsm_fwd_pass2<C>, l2);
     hipLaunchKernelGGL(hsm_fwd_pass1<C>, dim3(T, B), dim3(256), l1, st, x, w_bcdt, w_dw, part_ms, part_acc, Hs, tilesX);
     int rc = kmu::launch_status("hsmssd_fwd pass1");
     if (rc) return rc;

@@ -526,7 +526,7 @@ int launch_fwd(const float* x, const float* knots, const float* wp, const float*
     dim3 grid(tilesX * tilesY, NT / (WN * NREP), B);
     const size_t lds = G::LDS_FLOATS * sizeof(float);
     auto kern = kan_fwd_kernel<TH, TW, WM, WN, MREP, NREP>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    KMU_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, knots, wp, residual, y, Cin, Cout, H, W, CG, NT, tilesX,
                        relu);
     return kmu::launch_status("kan_conv2d_fwd");
@@ -541,7 +541,7 @@ int launch_bwd_input(const float* x, const float* dy, const float* knots, const 
     dim3 grid(tilesX * tilesY, CT / (WN * CREP), B);
     const size_t lds = (32 + (size_t)OG * 4 * G::OS) * sizeof(float);
     auto kern = kan_bwd_input_kernel<TH, TW, WM, WN, MREP, CREP>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    KMU_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, dy, knots, wq, dx, Cin, Cout, H, W, OG, CT, tilesX);
     return kmu::launch_status("kan_conv2d_bwd_input");
 }
@@ -630,7 +630,7 @@ extern "C" int kmu_kan_conv2d_bwd_weights(const float* x, const float* dy, const
     const int S = bwd_weight_splits(B, Cin, Cout, H, W);
     const int tilesX = kmu::cdiv(W, G::TW), tilesY = kmu::cdiv(H, G::TH);
     const size_t lds = G::LDS_FLOATS * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)kan_bwd_weight_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    KMU_MAX_LDS(kan_bwd_weight_kernel, lds);
     hipLaunchKernelGGL(kan_bwd_weight_kernel, dim3(S, OT, CT), dim3(256), lds, st, x, dy, knots, (float*)ws, B, Cin,
                        Cout, H, W, OT, S, tilesX, tilesY);
     int rc = kmu::launch_status("kan_conv2d_bwd_weights");

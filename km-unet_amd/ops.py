@@ -55,11 +55,14 @@ def _ptr(t):
 
 
 # ------------------------------------------------------------------------------------------ K1
+_GRID_OK = set()
+
+
 def _check_grid(grid):
     """KANLinear.grid is [in_features, 12] with identical rows (KANlayers.py:526-535).  The kernels
     share one knot vector; verified once per buffer version (host sync, so never inside a capture)."""
     key = (grid.data_ptr(), grid._version, tuple(grid.shape))
-    if getattr(_check_grid, "_ok", None) != key:
+    if key not in _GRID_OK:
         if grid.dim() != 2 or grid.shape[1] != 12:
             raise RuntimeError("KANConv2d: expected a [in_features, 12] knot buffer, got %s" % (tuple(grid.shape),))
         if not bool((grid == grid[0:1]).all()):
@@ -67,7 +70,7 @@ def _check_grid(grid):
                                "the HIP kernel supports one shared knot vector only")
         if not bool((grid[0, 1:] > grid[0, :-1]).all()):
             raise RuntimeError("KANConv2d: knots must be strictly increasing")
-        _check_grid._ok = key
+        _GRID_OK.add(key)
     return grid[0].contiguous()
 
 

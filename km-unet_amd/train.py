@@ -27,12 +27,55 @@ class TrainStep:
             kw.update(fused=True, capturable=capturable)
         self.opt = torch.optim.AdamW(live, **kw)
 
-    def __call__(self, data):
+    def forward_backward(self, data):
         inp, tgt = split_frames(data)
         self.dp.zero_grad()
         out = self.model(inp)
         loss = F.mse_loss(out, tgt)
         loss.backward()
+        return loss
+
+    def __call__(self, data):
+        loss = self.forward_backward(data)
         self.dp.all_reduce_grads()
         self.opt.step()
         return loss
+
+
+class GraphedTrainStep:
+    """The same step replayed from captured hipGraphs (torch.cuda.CUDAGraph): ~4.7k kernel launches per step
+    otherwise make the loop host-bound.  One process: a single graph holds zero-grad, forward, loss, backward
+    and the fused AdamW.  Several processes: graph 1 = zero-grad + forward + backward, then the (eager) RCCL
+    all-reduce of the flat gradient bucket, then graph 2 = AdamW -- the collective stays outside the capture.
+    Requires TrainStep(..., capturable=True); shapes are static; DropPath draws from the captured Philox stream."""
+
+    def __init__(self, step, example_data, warmup=3):
+        self.step = step
+        self.static_data = example_data.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step(self.static_data)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1 = torch.cuda.CUDAGraph()
+        self.g2 = None
+        if step.dp.world == 1:
+            with torch.cuda.graph(self.g1):
+                self.loss = step(self.static_data)
+        else:
+            with torch.cuda.graph(self.g1):
+                self.loss = step.forward_backward(self.static_data)
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2):
+                step.opt.step()
+
+    def __call__(self, data):
+        if data is not self.static_data:
+            self.static_data.copy_(data)
+        self.g1.replay()
+        if self.g2 is not None:
+            self.step.dp.all_reduce_grads()
+            self.g2.replay()
+        return self.loss
