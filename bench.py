@@ -106,12 +106,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    # KMU_DIST_BACKEND=gloo lets the N>1 code path be rehearsed with several ranks sharing one GPU
+    # (RCCL refuses two ranks on one device); the real runs use "nccl" (= RCCL over xGMI).
+    backend = os.environ.get("KMU_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import km_unet_amd
     from km_unet_amd import ops
@@ -126,6 +133,7 @@ def main():
     step = eager if args.no_graph else GraphedTrainStep(eager, data)
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
