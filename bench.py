@@ -164,11 +164,13 @@ def main():
                "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay"}
 
     # ---- roofline leg: extra instrumented steps, HIP events around every C-ABI launch ----------
+    # (every rank runs them -- a step contains the gradient all-reduce -- only rank 0 records and reports)
+    nprof = 3
     if rank == 0:
-        nprof = 3
         ops.profile_begin()
-        for _ in range(nprof):
-            eager(data)                      # eager: HIP events bracket each launch on the launch stream
+    for _ in range(nprof):
+        eager(data)                      # eager: HIP events bracket each launch on the launch stream
+    if rank == 0:
         prof = ops.profile_end()
         table = {}
         for (name, shape), ms_list in prof.items():
