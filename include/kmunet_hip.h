@@ -161,6 +161,33 @@ int kmu_dwconv3x3_partials(int B);
 int kmu_dwconv3x3_bwd_weight(const float* x, const float* dy, float* d_weight_partial, float* d_bias_partial, int B,
                              int C, int H, int W, kmu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused BatchNorm2d (+ReLU) (+ sigmoid-alpha blend): the elementwise chain around every conv of
+ * EfficientViMBlock (vim_block_init/efficient_vim_init.py:81-97; ConvLayer2D, vim_utils_init.py:62-89):
+ *     out = x + a*(f(t) - x),  a = sigmoid(alpha[c]),  f(t) = relu?(BatchNorm2d(t))   or   f(t) = t
+ * t, x, out: [B,C,HW].  gamma == NULL: no BatchNorm (the mixer blend, :90).  alpha == NULL: no blend
+ * (x ignored; FFN.fc1 = conv+BN+ReLU).  training != 0: batch statistics, running_mean/var updated with
+ * `momentum` (unbiased variance), as nn.BatchNorm2d.  stats [C,2] = (mean, rstd) saved for backward.
+ * ws: forward [C,S,2], backward [C,S,3] floats with S = kmu_bn_blend_splits(B, HW).
+ * backward: dt (and dx if blending) fully written; d_gamma/d_beta/d_alpha [C] (d_alpha is w.r.t. the RAW
+ * alpha, i.e. includes sigmoid'(alpha)).
+ * ------------------------------------------------------------------------------------ */
+int kmu_bn_blend_splits(int B, int HW);
+int kmu_bn_blend_fwd(const float* t, const float* x, const float* gamma, const float* beta, const float* alpha,
+                     float* running_mean, float* running_var, float momentum, float eps, int relu, int training,
+                     float* out, float* stats, float* ws, int B, int C, int HW, kmu_stream_t stream);
+int kmu_bn_blend_bwd(const float* gout, const float* t, const float* x, const float* gamma, const float* beta,
+                     const float* alpha, const float* stats, int relu, int training, float* dt, float* dx,
+                     float* d_gamma, float* d_beta, float* d_alpha, float* ws, int B, int C, int HW,
+                     kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * DirectionAttention's local gate  attn = sigmoid(q*k)*v  (KM_UNetV3_SH.py:258-261) on the packed output
+ * of the qkv 1x1 conv: qkv [B,3C,HW] -> out [B,C,HW]; backward writes dqkv [B,3C,HW] in full.  HW % 4 == 0.
+ * ------------------------------------------------------------------------------------ */
+int kmu_qkv_gate_fwd(const float* qkv, float* out, int B, int C, int HW, kmu_stream_t stream);
+int kmu_qkv_gate_bwd(const float* qkv, const float* gout, float* dqkv, int B, int C, int HW, kmu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,8 @@ SOURCES = [
     ("dysample.hip", ["-ffp-contract=off"]),
     ("deform_conv2d.hip", []),
     ("dwconv3x3.hip", []),
+    ("bn_blend.hip", []),
+    ("qkv_gate.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

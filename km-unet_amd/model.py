@@ -71,8 +71,13 @@ class DirectionAttention(nn.Module):
     def forward(self, x):
         b, c = x.shape[:2]
         gate = self.fc(x.mean(dim=(2, 3)))
-        q, k, v = conv1x1(x, self.qkv).chunk(3, dim=1)
-        return ops.dwconv3x3(torch.sigmoid(q * k) * v, self.conv.weight, self.conv.bias) * gate.view(b, c, 1, 1)
+        qkv = conv1x1(x, self.qkv)
+        if (qkv.shape[2] * qkv.shape[3]) % 4 == 0:
+            attn = ops.qkv_gate(qkv)                       # sigmoid(q*k)*v, one HIP kernel
+        else:
+            q, k, v = qkv.chunk(3, dim=1)
+            attn = torch.sigmoid(q * k) * v
+        return ops.dwconv3x3(attn, self.conv.weight, self.conv.bias) * gate.view(b, c, 1, 1)
 
 
 class DirectionViM(nn.Module):

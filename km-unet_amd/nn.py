@@ -140,15 +140,19 @@ class ConvLayer2D(nn.Module):
             nn.init.constant_(self.norm.weight, bn_weight_init)
             nn.init.constant_(self.norm.bias, 0)
 
-    def forward(self, x):
+    def conv_only(self, x):
         c = self.conv
         if c.groups == c.in_channels == c.out_channels and c.kernel_size == (3, 3) and c.stride == (1, 1) \
                 and c.padding == (1, 1) and c.dilation == (1, 1):
-            x = ops.dwconv3x3(x, c.weight, c.bias)          # HIP stencil instead of MIOpen's naive fallback
-        elif _is_pointwise(c):
-            x = conv1x1(x, c)
-        else:
-            x = c(x)
+            return ops.dwconv3x3(x, c.weight, c.bias)       # HIP stencil instead of MIOpen's naive fallback
+        if _is_pointwise(c):
+            return conv1x1(x, c)
+        return c(x)
+
+    def forward(self, x):
+        x = self.conv_only(x)
+        if isinstance(self.norm, nn.BatchNorm2d) and (self.act is None or isinstance(self.act, nn.ReLU)):
+            return ops.bn_blend(x, None, self.norm, None, 0, relu=self.act is not None)
         if self.norm:
             x = self.norm(x)
         return self.act(x) if self.act else x
@@ -199,12 +203,14 @@ class EfficientViMBlock(nn.Module):
         self.alpha = nn.Parameter(1e-4 * torch.ones(4, dim))
 
     def forward(self, x):
-        a = torch.sigmoid(self.alpha).view(4, -1, 1, 1)
-        x = torch.lerp(x, self.dwconv1(x), a[0])
+        # x <- (1-a_k) x + a_k f_k(x), a = sigmoid(alpha): each blend (and the BatchNorm / ReLU in front of it)
+        # is one fused HIP op (csrc/bn_blend.hip)
+        x = ops.bn_blend(self.dwconv1.conv_only(x), x, self.dwconv1.norm, self.alpha, 0)
         y, _ = self.mixer(self.norm(x.flatten(2)))
-        x = torch.lerp(x, y, a[1])
-        x = torch.lerp(x, self.dwconv2(x), a[2])
-        return torch.lerp(x, self.ffn(x), a[3])
+        x = ops.bn_blend(y, x, None, self.alpha, 1)
+        x = ops.bn_blend(self.dwconv2.conv_only(x), x, self.dwconv2.norm, self.alpha, 2)
+        h = self.ffn.fc1(x)
+        return ops.bn_blend(self.ffn.fc2.conv_only(h), x, self.ffn.fc2.norm, self.alpha, 3)
 
 
 # ------------------------------------------------------------------ DySample (K3)

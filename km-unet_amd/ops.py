@@ -357,3 +357,94 @@ class DwConv3x3Fn(torch.autograd.Function):
 
 def dwconv3x3(x, weight, bias=None):
     return DwConv3x3Fn.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------ BN + ReLU + blend
+class BnBlendFn(torch.autograd.Function):
+    """out = x + sigmoid(alpha[row]) * (f(t) - x),  f = relu?(BatchNorm2d(t)) or identity
+    (EfficientViMBlock.forward, efficient_vim_init.py:81-97, with ConvLayer2D's norm/act, vim_utils_init.py:62-89)."""
+
+    @staticmethod
+    def forward(ctx, t, x, gamma, beta, alpha, row, running_mean, running_var, momentum, eps, relu, training):
+        lib = _lib.load()
+        t = _f32c(t, "t")
+        x = _f32c(x, "x") if x is not None else None
+        B, C = t.shape[:2]
+        HW = t.numel() // (B * C)
+        dev = t.device
+        has_bn, has_blend = gamma is not None, alpha is not None
+        a_row = alpha[row] if has_blend else None
+        out = torch.empty_like(t)
+        S = lib.kmu_bn_blend_splits(B, HW)
+        stats = torch.empty(C, 2, device=dev, dtype=torch.float32) if has_bn else None
+        ws = torch.empty(C * S * 3, device=dev, dtype=torch.float32)
+        _lib.check(_call(("bn_blend_fwd", (B, C, HW)), lib.kmu_bn_blend_fwd, _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row),
+                         _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), int(relu), int(training), _ptr(out),
+                         _ptr(stats), _ptr(ws), B, C, HW, _stream()), "kmu_bn_blend_fwd")
+        ctx.save_for_backward(t, x, gamma, beta, alpha, stats)
+        ctx.cfg = (row, int(relu), int(training), B, C, HW, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        t, x, gamma, beta, alpha, stats = ctx.saved_tensors
+        row, relu, training, B, C, HW, S = ctx.cfg
+        g = _f32c(g, "grad")
+        dev = t.device
+        has_bn, has_blend = gamma is not None, alpha is not None
+        a_row = alpha[row] if has_blend else None
+        dt = torch.empty_like(t)
+        dx = torch.empty_like(t) if has_blend else None
+        dg = torch.empty(C, device=dev, dtype=torch.float32) if has_bn else None
+        db = torch.empty(C, device=dev, dtype=torch.float32) if has_bn else None
+        da = torch.zeros_like(alpha) if has_blend else None
+        ws = torch.empty(C * S * 3, device=dev, dtype=torch.float32)
+        _lib.check(_call(("bn_blend_bwd", (B, C, HW)), lib.kmu_bn_blend_bwd, _ptr(g), _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta),
+                         _ptr(a_row), _ptr(stats), relu, training, _ptr(dt), _ptr(dx), _ptr(dg), _ptr(db),
+                         _ptr(da[row]) if has_blend else None, _ptr(ws), B, C, HW, _stream()), "kmu_bn_blend_bwd")
+        return dt, dx, dg, db, da, None, None, None, None, None, None, None
+
+
+def bn_blend(t, x=None, bn=None, alpha=None, row=0, relu=False):
+    """t: conv output; x: blend partner (or None); bn: an nn.BatchNorm2d (or None); alpha: the raw [4, C]
+    layer-scale parameter (or None)."""
+    if bn is None:
+        return BnBlendFn.apply(t, x, None, None, alpha, row, None, None, 0.0, 0.0, relu, False)
+    training = bn.training
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    return BnBlendFn.apply(t, x, bn.weight, bn.bias, alpha, row, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu,
+                           training)
+
+
+# ------------------------------------------------------------------------------------------ sigmoid(q*k)*v
+class QkvGateFn(torch.autograd.Function):
+    """attn = sigmoid(q*k)*v on the packed qkv conv output (DirectionAttention.forward, KM_UNetV3_SH.py:258-261)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        lib = _lib.load()
+        qkv = _f32c(qkv, "qkv")
+        B, C3, H, W = qkv.shape
+        C = C3 // 3
+        out = torch.empty(B, C, H, W, device=qkv.device, dtype=torch.float32)
+        _lib.check(_call(("qkv_gate_fwd", (B, C, H * W)), lib.kmu_qkv_gate_fwd, _ptr(qkv), _ptr(out), B, C, H * W, _stream()),
+                   "kmu_qkv_gate_fwd")
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (qkv,) = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        B, C3, H, W = qkv.shape
+        d = torch.empty_like(qkv)
+        _lib.check(_call(("qkv_gate_bwd", (B, C3 // 3, H * W)), lib.kmu_qkv_gate_bwd, _ptr(qkv), _ptr(g), _ptr(d), B, C3 // 3, H * W,
+                         _stream()), "kmu_qkv_gate_bwd")
+        return d
+
+
+def qkv_gate(qkv):
+    return QkvGateFn.apply(qkv)

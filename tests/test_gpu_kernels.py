@@ -242,6 +242,63 @@ def test_dwconv3x3_vs_torch_cpu(B, C, H, W, bias):
     _report("dwconv %s" % ((B, C, H, W),), **errs)
 
 
+# ------------------------------------------------------------------------------------------ BN + ReLU + blend
+@pytest.mark.parametrize("B,C,H,bn,blend,relu,train", [(8, 16, 128, True, True, False, True), (2, 64, 8, True, False, True, True),
+                                                        (3, 32, 5, True, True, False, False), (2, 16, 16, False, True, False, True),
+                                                        (2, 64, 32, True, True, True, True)])
+def test_bn_blend_vs_torch_cpu(B, C, H, bn, blend, relu, train):
+    """out = lerp(x, relu?(BatchNorm2d(t)), sigmoid(alpha[row])) against nn.BatchNorm2d/ReLU/lerp on CPU,
+    forward, all gradients and the running statistics."""
+    import torch.nn as nn
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H)
+    t = (torch.randn(B, C, H, H, generator=gen) * 1.5 + 0.3).requires_grad_(True)
+    x = torch.randn(B, C, H, H, generator=gen).requires_grad_(True)
+    alpha = torch.randn(4, C, generator=gen).requires_grad_(True)
+    gy = torch.randn(B, C, H, H, generator=gen)
+    row = 2
+    m = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        m.weight.copy_(1 + 0.3 * torch.randn(C, generator=gen)); m.bias.copy_(0.2 * torch.randn(C, generator=gen))
+        m.running_mean.copy_(0.1 * torch.randn(C, generator=gen)); m.running_var.copy_(0.5 + torch.rand(C, generator=gen))
+    import copy
+    md = copy.deepcopy(m).to(DEV)
+    m.train(train); md.train(train)
+    f = m(t) if bn else t
+    if relu:
+        f = torch.relu(f)
+    yo = torch.lerp(x, f, torch.sigmoid(alpha[row]).view(1, C, 1, 1)) if blend else f
+    yo.backward(gy)
+    td, xd, ad = (v.detach().to(DEV).requires_grad_(True) for v in (t, x, alpha))
+    y = ops.bn_blend(td, xd if blend else None, md if bn else None, ad if blend else None, row, relu=relu)
+    y.backward(gy.to(DEV))
+    errs = {"y": rel_err(y, yo), "dt": rel_err(td.grad, t.grad)}
+    if blend:
+        errs["dx"] = rel_err(xd.grad, x.grad)
+        errs["dalpha"] = rel_err(ad.grad, alpha.grad)
+    if bn:
+        errs["dgamma"] = rel_err(md.weight.grad, m.weight.grad)
+        errs["dbeta"] = rel_err(md.bias.grad, m.bias.grad)
+        errs["rmean"] = rel_err(md.running_mean, m.running_mean)
+        errs["rvar"] = rel_err(md.running_var, m.running_var)
+        assert int(md.num_batches_tracked) == int(m.num_batches_tracked)
+    _report("bn_blend %s" % ((B, C, H, bn, blend, relu, train),), **errs)
+
+
+def test_qkv_gate_vs_torch_cpu():
+    ops = _ops()
+    gen = torch.Generator().manual_seed(5)
+    qkv = torch.randn(3, 48, 8, 8, generator=gen).requires_grad_(True)
+    gy = torch.randn(3, 16, 8, 8, generator=gen)
+    q, k, v = qkv.chunk(3, dim=1)
+    yo = torch.sigmoid(q * k) * v
+    yo.backward(gy)
+    d = qkv.detach().to(DEV).requires_grad_(True)
+    y = ops.qkv_gate(d)
+    y.backward(gy.to(DEV))
+    _report("qkv_gate", y=rel_err(y, yo), dqkv=rel_err(d.grad, qkv.grad))
+
+
 # ------------------------------------------------------------------------------------------ blocks
 @pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
 def test_evim_block_golden(name, train):
