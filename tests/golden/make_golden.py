@@ -163,7 +163,7 @@ def gen_iwp(ref):
 def gen_model(ref):
     for name, mod, variant, nc, train, b, hw in [
         ("model_sh_eval", ref.sh, "SH", 5, False, 1, 32),
-        ("model_sh_train", ref.sh, "SH", 5, True, 2, 32),
+        ("model_sh_train", ref.sh, "SH", 5, True, 2, 64),   # 64x64: >= 128 samples per BatchNorm channel at every level
         ("model_laps_eval", ref.laps, "LAPS", 3, False, 1, 32),
     ]:
         torch.manual_seed(0)

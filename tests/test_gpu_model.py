@@ -36,7 +36,7 @@ def test_whole_model_golden(name, variant, nc, train):
     assert sum(1 for _, p in m.named_parameters() if p.grad is None) == int(g["n_no_grad"])
     worst = ("", 0.0)
     for k in g:
-        if k.startswith("g__") and not k.endswith("__A"):
+        if k.startswith("g__") and not k.endswith("__A") and g[k].numel() > 1:   # scalars: checked by |grad| mass below
             e = rel_err(grads[k[3:].replace("__", ".")], g[k])
             worst = max(worst, (k, e), key=lambda t: t[1])
     bad = 0
