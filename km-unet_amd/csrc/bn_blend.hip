@@ -158,11 +158,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const float mean = gamma ? stats[c * 2] : 0.f, rstd = gamma ? stats[c * 2 + 1] : 1.f;
     const float g = gamma ? gamma[c] : 1.f, bt = gamma ? beta[c] : 0.f;
     const float a = alpha ? 1.f / (1.f + __expf(-alpha[c])) : 1.f;
+    const float scale = g * rstd, shift = bt - mean * scale;  // the forward's exact arithmetic => identical ReLU mask
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (long n = n0 + threadIdx.x; n < n1; n += 256) {
         const size_t o = off_of(n, c, C, HW);
         const float that = (t[o] - mean) * rstd;
-        float f = that * g + bt;
+        float f = t[o] * scale + shift;
         const bool on = !relu || f > 0.f;
         f = on ? f : 0.f;
         const float go = gout[o];
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     // train: dt = g*rstd*(dz - mean(dz) - that*mean(dz*that)) ; eval or no BN: dt = g*rstd*dz
     const float m0 = (gamma && training) ? (float)(p0 / (double)N) : 0.f;
     const float m1 = (gamma && training) ? (float)(p1 / (double)N) : 0.f;
-    const float k = g * rstd;
+    const float k = g * rstd, shift = bt - mean * k;
     for (long n = n0 + threadIdx.x; n < n1; n += 256) {
         const size_t o = off_of(n, c, C, HW);
         const float that = (t[o] - mean) * rstd;
-        const bool on = !relu || (that * g + bt) > 0.f;
+        const bool on = !relu || (t[o] * k + shift) > 0.f;  // same expression as bn_apply_kernel
         const float go = gout[o];
         const float dz = on ? a * go : 0.f;
         dt[o] = k * (dz - m0 - that * m1);

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, conv1x1
+from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1
 
 
 class DropPath(nn.Module):
@@ -72,11 +72,13 @@ class DirectionAttention(nn.Module):
         b, c = x.shape[:2]
         gate = self.fc(x.mean(dim=(2, 3)))
         qkv = conv1x1(x, self.qkv)
-        if (qkv.shape[2] * qkv.shape[3]) % 4 == 0:
+        if (qkv.shape[2] * qkv.shape[3]) % 4 == 0 and "qkv_gate" not in _TORCH_GLUE:
             attn = ops.qkv_gate(qkv)                       # sigmoid(q*k)*v, one HIP kernel
         else:
             q, k, v = qkv.chunk(3, dim=1)
             attn = torch.sigmoid(q * k) * v
+        if "dwconv" in _TORCH_GLUE:
+            return self.conv(attn) * gate.view(b, c, 1, 1)
         return ops.dwconv3x3(attn, self.conv.weight, self.conv.bias) * gate.view(b, c, 1, 1)
 
 

@@ -12,9 +12,18 @@ import torch.nn.functional as F
 from . import ops
 
 
+import os as _os
+
+# Debug only (tests/tools): comma list of fused glue ops to route back through stock PyTorch, e.g.
+# KMU_GLUE_TORCH=bn_blend,dwconv,conv1x1,qkv_gate -- used to bisect numerics; never set in production.
+_TORCH_GLUE = set(filter(None, _os.environ.get("KMU_GLUE_TORCH", "").split(",")))
+
+
 def conv1x1(x, conv):
     """1x1 convolution of an nn.Conv2d's parameters as ONE strided-batched GEMM  W[Co,Ci] @ x[b][Ci, H*W].
     (MIOpen serves NCHW 1x1 convs with im2col + batched transposes around a GEMM: 3-4 launches.)"""
+    if "conv1x1" in _TORCH_GLUE:
+        return conv(x)
     b, ci, h, w = x.shape
     co = conv.weight.shape[0]
     y = torch.bmm(conv.weight.view(1, co, ci).expand(b, co, ci), x.reshape(b, ci, h * w))
@@ -143,7 +152,7 @@ class ConvLayer2D(nn.Module):
     def conv_only(self, x):
         c = self.conv
         if c.groups == c.in_channels == c.out_channels and c.kernel_size == (3, 3) and c.stride == (1, 1) \
-                and c.padding == (1, 1) and c.dilation == (1, 1):
+                and c.padding == (1, 1) and c.dilation == (1, 1) and "dwconv" not in _TORCH_GLUE:
             return ops.dwconv3x3(x, c.weight, c.bias)       # HIP stencil instead of MIOpen's naive fallback
         if _is_pointwise(c):
             return conv1x1(x, c)
@@ -151,7 +160,8 @@ class ConvLayer2D(nn.Module):
 
     def forward(self, x):
         x = self.conv_only(x)
-        if isinstance(self.norm, nn.BatchNorm2d) and (self.act is None or isinstance(self.act, nn.ReLU)):
+        if isinstance(self.norm, nn.BatchNorm2d) and (self.act is None or isinstance(self.act, nn.ReLU)) \
+                and "bn_blend" not in _TORCH_GLUE:
             return ops.bn_blend(x, None, self.norm, None, 0, relu=self.act is not None)
         if self.norm:
             x = self.norm(x)
@@ -205,6 +215,13 @@ class EfficientViMBlock(nn.Module):
     def forward(self, x):
         # x <- (1-a_k) x + a_k f_k(x), a = sigmoid(alpha): each blend (and the BatchNorm / ReLU in front of it)
         # is one fused HIP op (csrc/bn_blend.hip)
+        if "bn_blend" in _TORCH_GLUE:
+            a = torch.sigmoid(self.alpha).view(4, -1, 1, 1)
+            x = torch.lerp(x, self.dwconv1(x), a[0])
+            y, _ = self.mixer(self.norm(x.flatten(2)))
+            x = torch.lerp(x, y, a[1])
+            x = torch.lerp(x, self.dwconv2(x), a[2])
+            return torch.lerp(x, self.ffn(x), a[3])
         x = ops.bn_blend(self.dwconv1.conv_only(x), x, self.dwconv1.norm, self.alpha, 0)
         y, _ = self.mixer(self.norm(x.flatten(2)))
         x = ops.bn_blend(y, x, None, self.alpha, 1)

@@ -44,6 +44,17 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def outlier_fraction(a, b, tol=1e-3):
+    """fraction of elements further than tol * max|b| from the reference"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs() > tol * b.abs().max().clamp_min(1e-30)).double().mean().item()
+
+
 @pytest.fixture
 def golden():
     return load_golden

