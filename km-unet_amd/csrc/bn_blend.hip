@@ -160,17 +160,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const float a = alpha ? 1.f / (1.f + __expf(-alpha[c])) : 1.f;
     const float scale = g * rstd, shift = bt - mean * scale;  // the forward's exact arithmetic => identical ReLU mask
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (long n = n0 + threadIdx.x; n < n1; n += 256) {
-        const size_t o = off_of(n, c, C, HW);
-        const float that = (t[o] - mean) * rstd;
-        float f = t[o] * scale + shift;
+    auto body = [&](float tv, float go, float xv) {
+        const float that = (tv - mean) * rstd;
+        float f = tv * scale + shift;
         const bool on = !relu || f > 0.f;
         f = on ? f : 0.f;
-        const float go = gout[o];
         const float dz = on ? a * go : 0.f;
         s0 += dz;
         s1 += dz * that;
-        if (x) s2 += go * (f - x[o]);
+        s2 += go * (f - xv);
+    };
+    if ((HW & 3) == 0) {
+        for (long n = n0 + threadIdx.x * 4; n < n1; n += 1024) {
+            const size_t o = off_of(n, c, C, HW);
+            const floatx4 tv = *reinterpret_cast<const floatx4*>(t + o), gv = *reinterpret_cast<const floatx4*>(gout + o);
+            floatx4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (x) xv = *reinterpret_cast<const floatx4*>(x + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) body(tv[k], gv[k], xv[k]);   // s2 is only consumed when x != NULL
+        }
+    } else {
+        for (long n = n0 + threadIdx.x; n < n1; n += 256) {
+            const size_t o = off_of(n, c, C, HW);
+            body(t[o], gout[o], x ? x[o] : 0.f);
+        }
     }
     s0 = block_sum(s0, red);
     s1 = block_sum(s1, red);
@@ -216,14 +229,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float m0 = (gamma && training) ? (float)(p0 / (double)N) : 0.f;
     const float m1 = (gamma && training) ? (float)(p1 / (double)N) : 0.f;
     const float k = g * rstd, shift = bt - mean * k;
-    for (long n = n0 + threadIdx.x; n < n1; n += 256) {
-        const size_t o = off_of(n, c, C, HW);
-        const float that = (t[o] - mean) * rstd;
-        const bool on = !relu || (t[o] * k + shift) > 0.f;  // same expression as bn_apply_kernel
-        const float go = gout[o];
+    auto one = [&](float tv, float go, float& dtv, float& dxv) {
+        const float that = (tv - mean) * rstd;
+        const bool on = !relu || (tv * k + shift) > 0.f;  // same expression as bn_apply_kernel
         const float dz = on ? a * go : 0.f;
-        dt[o] = k * (dz - m0 - that * m1);
-        if (dx) dx[o] = (1.f - a) * go;
+        dtv = k * (dz - m0 - that * m1);
+        dxv = (1.f - a) * go;
+    };
+    if ((HW & 3) == 0) {
+        for (long n = n0 + threadIdx.x * 4; n < n1; n += 1024) {
+            const size_t o = off_of(n, c, C, HW);
+            const floatx4 tv = *reinterpret_cast<const floatx4*>(t + o), gv = *reinterpret_cast<const floatx4*>(gout + o);
+            float dta[4], dxa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) one(tv[i], gv[i], dta[i], dxa[i]);
+            *reinterpret_cast<floatx4*>(dt + o) = floatx4{dta[0], dta[1], dta[2], dta[3]};
+            if (dx) *reinterpret_cast<floatx4*>(dx + o) = floatx4{dxa[0], dxa[1], dxa[2], dxa[3]};
+        }
+    } else {
+        for (long n = n0 + threadIdx.x; n < n1; n += 256) {
+            const size_t o = off_of(n, c, C, HW);
+            float dtv, dxv;
+            one(t[o], gout[o], dtv, dxv);
+            dt[o] = dtv;
+            if (dx) dx[o] = dxv;
+        }
     }
 }
 

@@ -82,20 +82,40 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const float* 
     float acc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    const int npix = max(0, y1 - y0) * W;
-    for (int p = threadIdx.x; p < npix; p += 256) {
-        const int y = y0 + p / W, xx = p % W;
-        const float g = gp[(size_t)y * W + xx];
-        acc[9] += g;
+    const int W4 = (W + 3) >> 2, nstrip = max(0, y1 - y0) * W4;
+    const bool vec_ok = (W & 3) == 0;
+    for (int sidx = threadIdx.x; sidx < nstrip; sidx += 256) {  // one strip = 4 consecutive pixels of a row
+        const int y = y0 + sidx / W4, x0 = (sidx % W4) * 4;
+        float g4[4];
+        if (vec_ok) {
+            const floatx4 gv = *reinterpret_cast<const floatx4*>(gp + (size_t)y * W + x0);
+            g4[0] = gv[0], g4[1] = gv[1], g4[2] = gv[2], g4[3] = gv[3];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g4[q] = (x0 + q < W) ? gp[(size_t)y * W + x0 + q] : 0.f;
+        }
+        acc[9] += (g4[0] + g4[1]) + (g4[2] + g4[3]);
 #pragma unroll
         for (int dyy = 0; dyy < 3; ++dyy) {
             const int yy = y + dyy - 1;
             if (yy < 0 || yy >= H) continue;
+            const float* row = xp + (size_t)yy * W;
+            float v[6];
+            if (vec_ok) {
+                const floatx4 m = *reinterpret_cast<const floatx4*>(row + x0);
+                v[1] = m[0], v[2] = m[1], v[3] = m[2], v[4] = m[3];
+                v[0] = x0 > 0 ? row[x0 - 1] : 0.f;
+                v[5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+            } else {
 #pragma unroll
-            for (int dxx = 0; dxx < 3; ++dxx) {
-                const int xc = xx + dxx - 1;
-                if (xc >= 0 && xc < W) acc[dyy * 3 + dxx] += g * xp[(size_t)yy * W + xc];
+                for (int k = 0; k < 6; ++k) {
+                    const int xx = x0 - 1 + k;
+                    v[k] = (xx >= 0 && xx < W) ? row[xx] : 0.f;
+                }
             }
+#pragma unroll
+            for (int dxx = 0; dxx < 3; ++dxx)
+                acc[dyy * 3 + dxx] += (g4[0] * v[dxx] + g4[1] * v[dxx + 1]) + (g4[2] * v[dxx + 2] + g4[3] * v[dxx + 3]);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -136,6 +136,75 @@ __global__ __launch_bounds__(256) void dysample_bwd_kernel(const float* __restri
     }
 }
 
+// Tiled backward: one workgroup = one 32x32 output tile of one (b, group).  Its samples land (for |offset| < ~2)
+// inside the 20x20 input window around the tile's 16x16 source pixels, so the scatter-add goes to an LDS window
+// (ds_add_f32) and is flushed to HBM once -- 16*400 global atomics per workgroup instead of 16*4*1024.
+// Samples outside the window (large learned offsets) fall back to direct global atomics: correct for any offset.
+constexpr int BT = 32, BWIN = BT / 2 + 4;  // output tile edge, input window edge
+
+__global__ __launch_bounds__(256) void dysample_bwd_tiled_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ conv_out,
+                                                                 const float* __restrict__ init_pos,
+                                                                 const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 float* __restrict__ d_conv_out, int C, int H, int W,
+                                                                 int tilesX) {
+    extern __shared__ __attribute__((aligned(16))) float win[];  // [cg][BWIN*BWIN]
+    const int OH = 2 * H, OW = 2 * W, cg = C / 4;
+    const int b = blockIdx.z, g = blockIdx.y;
+    const int oy0 = (blockIdx.x / tilesX) * BT, ox0 = (blockIdx.x % tilesX) * BT;
+    const int wy0 = oy0 / 2 - 2, wx0 = ox0 / 2 - 2;
+    for (int e = threadIdx.x; e < cg * BWIN * BWIN; e += 256) win[e] = 0.f;
+    __syncthreads();
+    const size_t hw = (size_t)H * W;
+    const size_t cbase = ((size_t)b * C + (size_t)g * cg) * hw;
+    for (int p = threadIdx.x; p < BT * BT; p += 256) {
+        const int oy = oy0 + p / BT, ox = ox0 + p % BT;
+        if (oy >= OH || ox >= OW) continue;
+        const Samp s = dys_coords(conv_out, init_pos, b, g, oy, ox, H, W);
+        const float w00 = (1.f - s.fx) * (1.f - s.fy), w01 = s.fx * (1.f - s.fy), w10 = (1.f - s.fx) * s.fy,
+                    w11 = s.fx * s.fy;
+        const bool inwin = s.y0 >= wy0 && s.y1 < wy0 + BWIN && s.x0 >= wx0 && s.x1 < wx0 + BWIN;
+        const int o00 = s.y0 * W + s.x0, o01 = s.y0 * W + s.x1, o10 = s.y1 * W + s.x0, o11 = s.y1 * W + s.x1;
+        const int l00 = (s.y0 - wy0) * BWIN + (s.x0 - wx0), l01 = (s.y0 - wy0) * BWIN + (s.x1 - wx0),
+                  l10 = (s.y1 - wy0) * BWIN + (s.x0 - wx0), l11 = (s.y1 - wy0) * BWIN + (s.x1 - wx0);
+        const float* dyp = dy + (((size_t)b * C + (size_t)g * cg) * OH + oy) * OW + ox;
+        float gpx = 0.f, gpy = 0.f;
+        for (int c = 0; c < cg; ++c) {
+            const float go = dyp[(size_t)c * OH * OW];
+            const float* xc = x + cbase + (size_t)c * hw;
+            const float v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
+            if (inwin) {
+                float* wc = win + c * BWIN * BWIN;
+                atomicAdd(wc + l00, go * w00);
+                atomicAdd(wc + l01, go * w01);
+                atomicAdd(wc + l10, go * w10);
+                atomicAdd(wc + l11, go * w11);
+            } else {
+                float* dxc = dx + cbase + (size_t)c * hw;
+                atomicAdd(dxc + o00, go * w00);
+                atomicAdd(dxc + o01, go * w01);
+                atomicAdd(dxc + o10, go * w10);
+                atomicAdd(dxc + o11, go * w11);
+            }
+            gpx += go * ((v01 - v00) * (1.f - s.fy) + (v11 - v10) * s.fy);
+            gpy += go * ((v10 - v00) * (1.f - s.fx) + (v11 - v01) * s.fx);
+        }
+        const int h = oy >> 1, i = oy & 1, w = ox >> 1, j = ox & 1;
+        const int chx = g * 4 + i * 2 + j, chy = 16 + chx;
+        const size_t pix = (size_t)h * W + w;
+        d_conv_out[((size_t)b * 32 + chx) * hw + pix] = s.in_x ? 0.25f * gpx : 0.f;
+        d_conv_out[((size_t)b * 32 + chy) * hw + pix] = s.in_y ? 0.25f * gpy : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cg * BWIN * BWIN; e += 256) {
+        const float v = win[e];
+        if (v == 0.f) continue;
+        const int c = e / (BWIN * BWIN), r = e % (BWIN * BWIN);
+        const int yy = wy0 + r / BWIN, xx = wx0 + r % BWIN;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(dx + cbase + (size_t)c * hw + (size_t)yy * W + xx, v);
+    }
+}
+
 int grid_for(size_t total) {
     size_t blocks = (total + 255) / 256;
     return (int)(blocks > 8192 ? 8192 : (blocks ? blocks : 1));
@@ -158,6 +227,14 @@ extern "C" int kmu_dysample_lp_bwd(const float* x, const float* conv_out, const 
                                    float* dx, float* d_conv_out, int B, int C, int H, int W, kmu_stream_t stream) {
     KMU_REQUIRE(x && conv_out && init_pos && dy && dx && d_conv_out, "dysample_lp_bwd: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "dysample_lp_bwd: bad dims");
+    const size_t lds = (size_t)(C / 4) * BWIN * BWIN * sizeof(float);
+    if (lds <= 64 * 1024 && B <= 65535) {
+        const int tilesX = kmu::cdiv(2 * W, BT), tilesY = kmu::cdiv(2 * H, BT);
+        KMU_MAX_LDS(dysample_bwd_tiled_kernel, lds);
+        hipLaunchKernelGGL(dysample_bwd_tiled_kernel, dim3(tilesX * tilesY, 4, B), dim3(256), lds, (hipStream_t)stream, x,
+                           conv_out, init_pos, dy, dx, d_conv_out, C, H, W, tilesX);
+        return kmu::launch_status("dysample_lp_bwd");
+    }
     const size_t total = (size_t)B * 4 * 2 * H * 2 * W;
     hipLaunchKernelGGL(dysample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, conv_out,
                        init_pos, dy, dx, d_conv_out, B, C, H, W);
