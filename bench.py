@@ -47,11 +47,13 @@ def kernel_model(name, shape):
     if name.startswith("hsmssd"):
         B, C, Hs = shape
         L, N = Hs * Hs, 64
-        flops = B * L * (2.0 * 3 * N * C + 2.0 * 9 * 3 * N + 4.0 * C * N)
-        byts = 4.0 * B * C * L * 2
-        if name.endswith("bwd"):
-            flops, byts = 3.0 * flops, 4.0 * B * C * L * 3
-        return "hbm", flops, byts
+        proj, dw, mix = 2.0 * N * C, 2.0 * 9 * N, 2.0 * C * N       # per token, per group of N rows of BCdt
+        per_token = {"fwd_pass1": (2 * proj + 2 * dw + mix, 1), "fwd_pass2": (proj + dw + mix, 2),
+                     "bwd_passA": (proj + dw + mix, 2), "bwd_passB": (3 * proj * 3 + 6 * dw + 4 * mix, 3)}
+        for key, (fl, tensors) in per_token.items():
+            if name.endswith(key):
+                return "hbm", B * L * fl, 4.0 * B * C * L * tensors  # tensors = algorithmic [B,C,L] reads + writes
+        return "hbm", 0.0, 4.0 * B * C * N * 8
     if name.startswith("dysample"):
         B, C, H, W = shape
         byts = 4.0 * B * C * H * W * 5 + 4.0 * B * 32 * H * W

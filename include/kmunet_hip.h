@@ -104,6 +104,12 @@ int kmu_hsmssd_fwd(const float* x, const float* w_bcdt, const float* w_dw, const
                    const float* D, float* y /*[B,C,Hs,Hs]*/, float* h /*[B,C,N]*/, float* state, void* ws,
                    size_t ws_bytes, int B, int C, int N, int Hs, kmu_stream_t stream);
 
+/* the same forward, one kernel per call: stage 0 = pass 1, 1 = gate, 2 = pass 2 (call in order, same arguments);
+ * used by the host wrapper so that each kernel can be timed / profiled on its own */
+int kmu_hsmssd_fwd_stage(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
+                         const float* D, float* y, float* h, float* state, void* ws, size_t ws_bytes, int B, int C,
+                         int N, int Hs, int stage, kmu_stream_t stream);
+
 size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs);
 /* number of per-workgroup partial slabs written for d_w_bcdt / d_w_dw (caller sums over dim 0) */
 int kmu_hsmssd_bwd_partials(int B, int C, int Hs);
@@ -115,6 +121,13 @@ int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh /*may be NUL
                    float* d_w_hz_partial /*[G,2C,C]*/, float* d_w_out_partial /*[G,C,C]*/,
                    float* d_D_partial /*[G]*/, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,
                    kmu_stream_t stream);
+
+/* stage 0 = pass A, 1 = gate, 2 = pass B (call in order, same arguments) */
+int kmu_hsmssd_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
+                         const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
+                         float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
+                         float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage,
+                         kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K3  DySample x2, style 'lp', 4 groups  (DySample_md.py:49-68).
@@ -187,6 +200,18 @@ int kmu_bn_blend_bwd(const float* gout, const float* t, const float* x, const fl
  * ------------------------------------------------------------------------------------ */
 int kmu_qkv_gate_fwd(const float* qkv, float* out, int B, int C, int HW, kmu_stream_t stream);
 int kmu_qkv_gate_bwd(const float* qkv, const float* gout, float* dqkv, int B, int C, int HW, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm(G, C) over [B,C,HW]: StableHybridKANConv.pre_norm (KM_UNetV3_SH.py:57,73), TripleNorm.norm_h/w
+ * (:271-273), MultiScaleFusion (:294), KM_UNetV3.output_norm (:448,516).  stats [B,G,2] = (mean, rstd);
+ * ws: [B*C*S*2] floats, S = kmu_group_norm_splits(HW); d_gamma/d_beta leave as [B,C] partials.
+ * ------------------------------------------------------------------------------------ */
+int kmu_group_norm_splits(int HW);
+int kmu_group_norm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* ws, int B,
+                       int C, int G, int HW, float eps, kmu_stream_t stream);
+int kmu_group_norm_bwd(const float* x, const float* gout, const float* gamma, const float* stats, float* dx,
+                       float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW,
+                       kmu_stream_t stream);
 
 #ifdef __cplusplus
 }

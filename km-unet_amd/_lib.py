@@ -30,6 +30,8 @@ SIGNATURES = {
     "kmu_hsmssd_state_elems": (_Z, [_I] * 3),
     "kmu_hsmssd_fwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_hsmssd_fwd": (_I, [_P] * 10 + [_Z] + [_I] * 4 + [_P]),
+    "kmu_hsmssd_fwd_stage": (_I, [_P] * 10 + [_Z] + [_I] * 5 + [_P]),
+    "kmu_hsmssd_bwd_stage": (_I, [_P] * 16 + [_Z] + [_I] * 5 + [_P]),
     "kmu_hsmssd_bwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_hsmssd_bwd_partials": (_I, [_I] * 3),
     "kmu_hsmssd_gate_partials": (_I, [_I]),
@@ -43,6 +45,9 @@ SIGNATURES = {
     "kmu_bn_blend_bwd": (_I, [_P] * 7 + [_I, _I] + [_P] * 6 + [_I] * 3 + [_P]),
     "kmu_qkv_gate_fwd": (_I, [_P] * 2 + [_I] * 3 + [_P]),
     "kmu_qkv_gate_bwd": (_I, [_P] * 3 + [_I] * 3 + [_P]),
+    "kmu_group_norm_splits": (_I, [_I]),
+    "kmu_group_norm_fwd": (_I, [_P] * 6 + [_I] * 4 + [_c.c_float, _P]),
+    "kmu_group_norm_bwd": (_I, [_P] * 8 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_fwd": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_bwd_data": (_I, [_P] * 3 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_partials": (_I, [_I]),

@@ -25,6 +25,7 @@ SOURCES = [
     ("dwconv3x3.hip", []),
     ("bn_blend.hip", []),
     ("qkv_gate.hip", []),
+    ("group_norm.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

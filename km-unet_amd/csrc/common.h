@@ -36,6 +36,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Tied-operand fp32 MFMA (vdst == srcC by construction).  With the builtin, hipcc (ROCm 7.2) sometimes rotates
+// loop-carried accumulators through v_accvgpr_write/mov placed right behind an MFMA that still reads them as
+// SrcC -- a WAR hazard it does not always pad (tools/check_mfma_overlap.py; it corrupted K2's d_w_bcdt at C=64).
+// Hand-placed wait states (cdna_hip_programming.md 5.7): `s_nop 1` ahead of each MFMA covers a VALU-written A/B
+// operand; mfma_drain() before the first non-MFMA reader covers the 8-pass result latency.
+__device__ __forceinline__ void mfma_tied(floatx4& acc, float a, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain(floatx4& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+
 }  // namespace kmu
 
 // Raise a kernel's dynamic-LDS limit once per call site / template instantiation (never during a later

@@ -474,25 +474,34 @@ inline int tiles_for(int C, int Hs, int* tilesX) {
     return *tilesX * kmu::cdiv(Hs, TY);
 }
 
+// stages: bit 0 = pass 1, bit 1 = gate, bit 2 = pass 2 (7 = the whole forward)
 template <int C>
 int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
-             const float* D, float* y, float* h, float* state, float* ws, int B, int Hs, hipStream_t st) {
+             const float* D, float* y, float* h, float* state, float* ws, int B, int Hs, int stages, hipStream_t st) {
     int tilesX;
     const int T = tiles_for(C, Hs, &tilesX);
     float* part_ms = ws;
     float* part_acc = ws + (size_t)B * T * 2 * NS;
     const size_t l1 = lds_pass1<C>(), l2 = lds_pass2<C>();
-    KMU_MAX_LDS(hsm_fwd_pass1<C>, l1);
-    KMU_MAX_LDS(hsm_fwd_pass2<C>, l2);
-    hipLaunchKernelGGL(hsm_fwd_pass1<C>, dim3(T, B), dim3(256), l1, st, x, w_bcdt, w_dw, part_ms, part_acc, Hs, tilesX);
-    int rc = kmu::launch_status("hsmssd_fwd pass1");
-    if (rc) return rc;
-    const size_t lg = ((size_t)2 * GN + 4 * C * GN) * sizeof(float);
-    hipLaunchKernelGGL(hsm_fwd_gate, dim3(B, NGRP), dim3(256), lg, st, part_ms, part_acc, w_hz, w_out, D, state, h, C, T);
-    rc = kmu::launch_status("hsmssd_fwd gate");
-    if (rc) return rc;
-    hipLaunchKernelGGL(hsm_fwd_pass2<C>, dim3(T, B), dim3(256), l2, st, x, w_bcdt, w_dw, state, y, Hs, tilesX);
-    return kmu::launch_status("hsmssd_fwd pass2");
+    int rc = 0;
+    if (stages & 1) {
+        KMU_MAX_LDS(hsm_fwd_pass1<C>, l1);
+        hipLaunchKernelGGL(hsm_fwd_pass1<C>, dim3(T, B), dim3(256), l1, st, x, w_bcdt, w_dw, part_ms, part_acc, Hs, tilesX);
+        rc = kmu::launch_status("hsmssd_fwd pass1");
+        if (rc) return rc;
+    }
+    if (stages & 2) {
+        const size_t lg = ((size_t)2 * GN + 4 * C * GN) * sizeof(float);
+        hipLaunchKernelGGL(hsm_fwd_gate, dim3(B, NGRP), dim3(256), lg, st, part_ms, part_acc, w_hz, w_out, D, state, h, C, T);
+        rc = kmu::launch_status("hsmssd_fwd gate");
+        if (rc) return rc;
+    }
+    if (stages & 4) {
+        KMU_MAX_LDS(hsm_fwd_pass2<C>, l2);
+        hipLaunchKernelGGL(hsm_fwd_pass2<C>, dim3(T, B), dim3(256), l2, st, x, w_bcdt, w_dw, state, y, Hs, tilesX);
+        rc = kmu::launch_status("hsmssd_fwd pass2");
+    }
+    return rc;
 }
 
 #include "hsmssd_bwd.inc"
@@ -507,18 +516,30 @@ extern "C" size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs) {
     return (size_t)B * T * ((size_t)2 * N + (size_t)N * C) * sizeof(float);
 }
 
-extern "C" int kmu_hsmssd_fwd(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
-                              const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
-                              size_t ws_bytes, int B, int C, int N, int Hs, kmu_stream_t stream) {
+static int hsmssd_fwd_stages(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                             const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
+                             size_t ws_bytes, int B, int C, int N, int Hs, int stages, kmu_stream_t stream) {
     KMU_REQUIRE(x && w_bcdt && w_dw && w_hz && w_out && D && y && h && state && ws, "hsmssd_fwd: null pointer");
     KMU_REQUIRE(N == NS, "hsmssd_fwd: state_dim=%d unsupported (kernels are built for 64)", N);
     KMU_REQUIRE(C == 16 || C == 32 || C == 64, "hsmssd_fwd: C=%d unsupported (16/32/64)", C);
     KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0, "hsmssd_fwd: bad dims");
     KMU_REQUIRE(ws_bytes >= kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs), "hsmssd_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (C == 16) return fwd_impl<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, st);
-    if (C == 32) return fwd_impl<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, st);
-    return fwd_impl<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, st);
+    if (C == 16) return fwd_impl<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
+    if (C == 32) return fwd_impl<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
+    return fwd_impl<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
+}
+
+extern "C" int kmu_hsmssd_fwd(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                              const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
+                              size_t ws_bytes, int B, int C, int N, int Hs, kmu_stream_t stream) {
+    return hsmssd_fwd_stages(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, ws, ws_bytes, B, C, N, Hs, 7, stream);
+}
+extern "C" int kmu_hsmssd_fwd_stage(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                                    const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
+                                    size_t ws_bytes, int B, int C, int N, int Hs, int stage, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_fwd_stage: stage must be 0 (pass 1), 1 (gate) or 2 (pass 2)");
+    return hsmssd_fwd_stages(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream);
 }
 
 extern "C" int kmu_layernorm1d_partials(int B, int L) { return B * kmu::cdiv(L, 256); }
@@ -553,11 +574,11 @@ extern "C" int kmu_hsmssd_bwd_partials(int B, int C, int Hs) {
     int tx;
     return B * tilesB_for(C, Hs, &tx);
 }
-extern "C" int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
-                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
-                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
-                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
-                              int Hs, kmu_stream_t stream) {
+static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
+                             const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
+                             float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
+                             float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
+                             int Hs, int stages, kmu_stream_t stream) {
     KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial &&
                     d_w_hz_partial && d_w_out_partial && d_D_partial && ws,
                 "hsmssd_bwd: null pointer");
@@ -569,10 +590,28 @@ extern "C" int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh, 
     float* w = (float*)ws;
     if (C == 16)
         return bwd_impl<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                            d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, st);
+                            d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
     if (C == 32)
         return bwd_impl<32>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                            d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, st);
+                            d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
     return bwd_impl<64>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                        d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, st);
+                        d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
+}
+
+extern "C" int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
+                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
+                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
+                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
+                              int Hs, kmu_stream_t stream) {
+    return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                             d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 7, stream);
+}
+extern "C" int kmu_hsmssd_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt,
+                                    const float* w_dw, const float* w_hz, const float* w_out, const float* D,
+                                    const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
+                                    float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, void* ws,
+                                    size_t ws_bytes, int B, int C, int N, int Hs, int stage, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_bwd_stage: stage must be 0 (pass A), 1 (gate) or 2 (pass B)");
+    return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                             d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream);
 }

@@ -202,25 +202,45 @@ __global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ 
         }
         __syncthreads();
         const float* wpc = wp + ((size_t)cg * 81 * NT + nt0) * 64 + lane;
+        // B fragments (packed weights, L2-resident) are double-buffered in registers: the 9 taps of basis j+1
+        // are requested before the 9x MREP x NREP MFMAs of basis j issue, so their L2 latency hides under them.
+        float bcur[9][NREP], bnxt[9][NREP];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bcur[tap][n] = wpc[((size_t)tap * NT + n) * 64];
+#pragma unroll
         for (int j = 0; j < NBASIS; ++j) {
+            if (j + 1 < NBASIS) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) bnxt[tap][n] = wpc[((size_t)((j + 1) * 9 + tap) * NT + n) * 64];
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                float bf[NREP];
-#pragma unroll
-                for (int n = 0; n < NREP; ++n) bf[n] = wpc[((size_t)(j * 9 + tap) * NT + n) * 64];
 #pragma unroll
                 for (int m = 0; m < MREP; ++m) {
                     const float a = phi[aoff[m] + j * HT + ky * RS + kx];
 #pragma unroll
-                    for (int n = 0; n < NREP; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NREP; ++n) kmu::mfma_tied(acc[m][n], a, bcur[tap][n]);
                 }
+            }
+            if (j + 1 < NBASIS) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) bcur[tap][n] = bnxt[tap][n];
             }
         }
     }
 
     // epilogue: lane holds 4 consecutive pixels (rows of the C tile) of output channel nt*16 + li
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) kmu::mfma_drain(acc[m][n]);
     const bool vec_ok = (W & 3) == 0;
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {

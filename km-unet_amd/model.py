@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1
+from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1, group_norm
 
 
 class DropPath(nn.Module):
@@ -53,7 +53,7 @@ class StableHybridKANConv(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
-        x = self.pre_norm(x)
+        x = group_norm(x, self.pre_norm)
         res = x if isinstance(self.residual, nn.Identity) else conv1x1(x, self.residual)
         return self.kanconv2d[0](x, residual=res, relu=True)
 
@@ -111,7 +111,7 @@ class TripleNorm(nn.Module):
 
     def forward(self, x):
         c = self.norm_c(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
-        return (self.norm_h(x) + self.norm_w(x) + c) / 3
+        return (group_norm(x, self.norm_h) + group_norm(x, self.norm_w) + c) / 3
 
 
 class EnhancedViMBlock(nn.Module):
@@ -160,7 +160,7 @@ class MultiScaleFusion(nn.Module):
         self.fusion = nn.Sequential(nn.Conv2d(co * 3, co, 1), nn.Conv2d(co, co, 3, padding=1), ChannelAttention(co, reduction))
 
     def forward(self, features):
-        return self.fusion(torch.cat([blk(f) for blk, f in zip(self.blocks, features)], dim=1))
+        return self.fusion(torch.cat([F.silu(group_norm(blk[0](f), blk[1])) for blk, f in zip(self.blocks, features)], dim=1))
 
 
 class LocalContrastAttention(nn.Module):
@@ -223,4 +223,4 @@ class KM_UNetV3(nn.Module):
         d1 = torch.cat([d1, self._pyramid(self.attention1, e1, e2, d1)], dim=1)
         d2 = self.dec2(d1)
         d2 = torch.cat([d2, self._pyramid(self.attention2, e1, e2, d2)], dim=1)
-        return self.activation(self.output_norm(self.dec3(d2)))
+        return self.activation(group_norm(self.dec3(d2), self.output_norm))

@@ -32,6 +32,13 @@ def conv1x1(x, conv):
     return y.view(b, co, h, w)
 
 
+def group_norm(x, gn):
+    """nn.GroupNorm through the HIP kernels (csrc/group_norm.hip); KMU_GLUE_TORCH=group_norm keeps ATen's."""
+    if "group_norm" in _TORCH_GLUE:
+        return gn(x)
+    return ops.group_norm(x, gn)
+
+
 def _is_pointwise(c):
     return c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and c.groups == 1
 

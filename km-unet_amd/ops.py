@@ -191,9 +191,11 @@ class HsmssdFn(torch.autograd.Function):
         state = torch.empty(lib.kmu_hsmssd_state_elems(B, C, N), device=dev, dtype=torch.float32)
         nbytes = lib.kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs)
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
-        _lib.check(_call(("hsmssd_fwd", (B, C, Hs)), lib.kmu_hsmssd_fwd, _ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
-                         _ptr(w_out), _ptr(D), _ptr(y), _ptr(h), _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, _stream()),
-                   "kmu_hsmssd_fwd")
+        st = _stream()
+        for stage, nm in enumerate(("hsmssd_fwd_pass1", "hsmssd_fwd_gate", "hsmssd_fwd_pass2")):   # one kernel per call
+            _lib.check(_call((nm, (B, C, Hs)), lib.kmu_hsmssd_fwd_stage, _ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
+                             _ptr(w_out), _ptr(D), _ptr(y), _ptr(h), _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, stage, st),
+                       "kmu_hsmssd_fwd_stage")
         ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
         ctx.dims = (B, C, N, Hs)
         ctx.A_shape = A.shape
@@ -217,9 +219,11 @@ class HsmssdFn(torch.autograd.Function):
         p_D = torch.empty(G, device=dev, dtype=torch.float32)
         nbytes = lib.kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
-        _lib.check(_call(("hsmssd_bwd", (B, C, Hs)), lib.kmu_hsmssd_bwd, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
-                         _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
-                         _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, _stream()), "kmu_hsmssd_bwd")
+        st = _stream()
+        for stage, nm in enumerate(("hsmssd_bwd_passA", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
+            _lib.check(_call((nm, (B, C, Hs)), lib.kmu_hsmssd_bwd_stage, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
+                             _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
+                             _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, st), "kmu_hsmssd_bwd_stage")
         # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd
         # returns ~1e-7 rounding noise here)
         return (dx, p_bcdt.sum(0).view(3 * N, C, 1), p_dw.sum(0).view(3 * N, 1, 3, 3), p_hz.sum(0).view(2 * C, C, 1),
@@ -448,3 +452,43 @@ class QkvGateFn(torch.autograd.Function):
 
 def qkv_gate(qkv):
     return QkvGateFn.apply(qkv)
+
+
+# ------------------------------------------------------------------------------------------ GroupNorm
+class GroupNormFn(torch.autograd.Function):
+    """nn.GroupNorm(G, C) forward/backward (KM_UNetV3_SH.py:57,271-273,294,448)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps):
+        lib = _lib.load()
+        x, gamma, beta = _f32c(x, "x"), _f32c(gamma, "weight"), _f32c(beta, "bias")
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        S = lib.kmu_group_norm_splits(HW)
+        y = torch.empty_like(x)
+        stats = torch.empty(B, G, 2, device=x.device, dtype=torch.float32)
+        ws = torch.empty(B * C * S * 2, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("group_norm_fwd", (B, C, G, HW)), lib.kmu_group_norm_fwd, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y),
+                         _ptr(stats), _ptr(ws), B, C, G, HW, float(eps), _stream()), "kmu_group_norm_fwd")
+        ctx.save_for_backward(x, gamma, stats)
+        ctx.cfg = (B, C, G, HW, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, gamma, stats = ctx.saved_tensors
+        B, C, G, HW, S = ctx.cfg
+        g = _f32c(g, "grad")
+        dx = torch.empty_like(x)
+        dgp = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        dbp = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(B * C * S * 2, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("group_norm_bwd", (B, C, G, HW)), lib.kmu_group_norm_bwd, _ptr(x), _ptr(g), _ptr(gamma), _ptr(stats),
+                         _ptr(dx), _ptr(dgp), _ptr(dbp), _ptr(ws), B, C, G, HW, _stream()), "kmu_group_norm_bwd")
+        return dx, dgp.sum(0), dbp.sum(0), None, None
+
+
+def group_norm(x, gn):
+    """gn: an nn.GroupNorm module (parameters + num_groups + eps)."""
+    return GroupNormFn.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps)

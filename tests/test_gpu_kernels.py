@@ -285,6 +285,25 @@ def test_bn_blend_vs_torch_cpu(B, C, H, bn, blend, relu, train):
     _report("bn_blend %s" % ((B, C, H, bn, blend, relu, train),), **errs)
 
 
+@pytest.mark.parametrize("B,C,G,H", [(8, 16, 4, 128), (2, 64, 1, 16), (3, 5, 1, 10), (2, 32, 4, 7)])
+def test_group_norm_vs_torch_cpu(B, C, G, H):
+    import copy
+    import torch.nn as nn
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, H, generator=gen) * 1.3 + 0.4).requires_grad_(True)
+    gy = torch.randn(B, C, H, H, generator=gen)
+    m = nn.GroupNorm(G, C)
+    with torch.no_grad():
+        m.weight.copy_(1 + 0.3 * torch.randn(C, generator=gen)); m.bias.copy_(0.2 * torch.randn(C, generator=gen))
+    md = copy.deepcopy(m).to(DEV)
+    yo = m(x); yo.backward(gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.group_norm(xd, md); y.backward(gy.to(DEV))
+    _report("group_norm %s" % ((B, C, G, H),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad),
+            dgamma=rel_err(md.weight.grad, m.weight.grad), dbeta=rel_err(md.bias.grad, m.bias.grad))
+
+
 def test_qkv_gate_vs_torch_cpu():
     ops = _ops()
     gen = torch.Generator().manual_seed(5)
