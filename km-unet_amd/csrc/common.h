@@ -24,17 +24,40 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// wave64 all-reduce helpers (DPP/bpermute via __shfl_xor)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// wave64 reductions on DPP (VALU-rate row shifts + row broadcasts; __shfl_xor lowers to ds_bpermute = an LDS
+// round trip per step).  Sequence: row_shr 1,2,4,8 leaves each 16-lane row's total in its lane 15; row_bcast:15 adds
+// it into the next row (lanes 31 / 63 then hold their 32-lane half's total); row_bcast:31 completes lane 63.
+// Out-of-row sources read `identity` (old operand, bound_ctrl off).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+struct OpSum {
+    static __device__ __forceinline__ float id() { return 0.f; }
+    static __device__ __forceinline__ float f(float a, float b) { return a + b; }
+};
+struct OpMax {
+    static __device__ __forceinline__ float id() { return -INFINITY; }
+    static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); }
+};
+// WIDTH = 64: total over the wave; WIDTH = 32: total over each 32-lane half.  Result broadcast to every lane of the group.
+template <class Op, int WIDTH>
+__device__ __forceinline__ float wave_reduce(float v) {
+    v = Op::f(v, dpp_mov<0x111, 0xf>(Op::id(), v));  // row_shr:1
+    v = Op::f(v, dpp_mov<0x112, 0xf>(Op::id(), v));  // row_shr:2
+    v = Op::f(v, dpp_mov<0x114, 0xf>(Op::id(), v));  // row_shr:4
+    v = Op::f(v, dpp_mov<0x118, 0xf>(Op::id(), v));  // row_shr:8
+    v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));  // row_bcast:15 -> rows 1, 3
+    if (WIDTH == 64) {
+        v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));  // row_bcast:31 -> rows 2, 3
+        return __builtin_amdgcn_readlane(v, 63);
+    }
+    const float lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    return (threadIdx.x & 32) ? hi : lo;
 }
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce<OpSum, 64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce<OpMax, 64>(v); }
 
 // Tied-operand fp32 MFMA (vdst == srcC by construction).  With the builtin, hipcc (ROCm 7.2) sometimes rotates
 // loop-carried accumulators through v_accvgpr_write/mov placed right behind an MFMA that still reads them as

@@ -108,15 +108,13 @@ __device__ __forceinline__ void dw_strip(const float* Prow, const float* __restr
 
 template <int WIDTH>
 __device__ __forceinline__ float grp_max(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    static_assert(WIDTH == 64 || WIDTH == 32, "strip groups are a wave or a half wave");
+    return kmu::wave_reduce<kmu::OpMax, WIDTH>(v);
 }
 template <int WIDTH>
 __device__ __forceinline__ float grp_sum(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    static_assert(WIDTH == 64 || WIDTH == 32, "strip groups are a wave or a half wave");
+    return kmu::wave_reduce<kmu::OpSum, WIDTH>(v);
 }
 
 // =================================================================================================
@@ -257,8 +255,10 @@ __global__ __launch_bounds__(256) void hsm_fwd_gate(const float* __restrict__ pa
     if (tid < GN) {
         const int n = nb + tid;
         float M = -INFINITY;
+#pragma unroll 8
         for (int t = 0; t < T; ++t) M = fmaxf(M, pms[(size_t)t * 2 * NS + n]);
         float S = 0.f;
+#pragma unroll 8
         for (int t = 0; t < T; ++t) S += pms[(size_t)t * 2 * NS + NS + n] * __expf(pms[(size_t)t * 2 * NS + n] - M);
         Ms[tid] = M;
         Ss[tid] = S;
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void hsm_fwd_gate(const float* __restrict__ pa
     for (int e = tid; e < C * GN; e += 256) {  // e = nl*C + c (the partial layout is [n][C])
         const int nl = e / C, c = e - nl * C, n = nb + nl;
         float a = 0.f;
+#pragma unroll 8
         for (int t = 0; t < T; ++t) a += pac[(size_t)t * NS * C + n * C + c] * __expf(pms[(size_t)t * 2 * NS + n] - Ms[nl]);
         a /= Ss[nl];
         hp[c * GN + nl] = a;
