@@ -33,6 +33,9 @@ __device__ __forceinline__ float dpp_mov(float identity, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
                                                                  CTRL, ROW_MASK, 0xf, false));
 }
+__device__ __forceinline__ float readlane_f(float v, int lane) {  // the builtin is int -> int: bit-cast, never convert
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 struct OpSum {
     static __device__ __forceinline__ float id() { return 0.f; }
     static __device__ __forceinline__ float f(float a, float b) { return a + b; }
@@ -51,9 +54,9 @@ __device__ __forceinline__ float wave_reduce(float v) {
     v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));  // row_bcast:15 -> rows 1, 3
     if (WIDTH == 64) {
         v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));  // row_bcast:31 -> rows 2, 3
-        return __builtin_amdgcn_readlane(v, 63);
+        return readlane_f(v, 63);
     }
-    const float lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    const float lo = readlane_f(v, 31), hi = readlane_f(v, 63);
     return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce<OpSum, 64>(v); }
