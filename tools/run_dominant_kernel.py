@@ -1,0 +1,26 @@
+"""Launch the step's dominant hand-written kernels in isolation (for rocprofv3 --pmc passes):
+K2 forward + backward at the bench shape (B=8, C=16, 128x128) and K1 forward at site 1."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import km_unet_amd
+from km_unet_amd import ops
+
+torch.manual_seed(0)
+d = "cuda"
+B, C, Hs, N = 8, 16, 128, 64
+x = torch.randn(B, C, Hs * Hs, device=d, requires_grad=True)
+w = [torch.randn(3 * N, C, 1, device=d) / 4, torch.randn(3 * N, 1, 3, 3, device=d) * 0.3, torch.randn(2 * C, C, 1, device=d) / 4,
+     torch.randn(C, C, 1, device=d) / 4, torch.ones(N, device=d), torch.ones(1, device=d)]
+w = [t.requires_grad_(True) for t in w]
+gy = torch.randn(B, C, Hs, Hs, device=d)
+xk = torch.randn(B, 16, 128, 128, device=d)
+grid = km_unet_amd.KANLinear(144, 16).grid.to(d)
+kw = [torch.randn(16, 144, device=d) * 0.1, torch.randn(16, 144, 8, device=d) * 0.1, torch.randn(16, 144, device=d)]
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    y, h = ops.hsmssd(x, *w)
+    y.backward(gy)
+    ops.kan_conv2d(xk, grid, *kw)
+torch.cuda.synchronize()
+print("done")
