@@ -35,8 +35,32 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
 
 
+RIDGE = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # FLOP/B at which fp32 MFMA and HBM roofs cross (19.7)
+
+
+def pmc_traffic(name, shape):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01b_pmc_traffic.json), measured at
+    the bench shape only; None for kernels / shapes without a PMC pass."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))["kernels"]
+    except Exception:
+        return None
+    key = {("hsmssd_bwd_passB", (8, 16, 128)): "hsm_bwd_passB<16>", ("hsmssd_bwd_passA", (8, 16, 128)): "hsm_bwd_passA<16>",
+           ("hsmssd_fwd_pass1", (8, 16, 128)): "hsm_fwd_pass1<16>", ("hsmssd_fwd_pass2", (8, 16, 128)): "hsm_fwd_pass2<16>",
+           ("kan_conv2d_fwd", (8, 16, 16, 128, 128)): "kan_fwd_kernel<8, 32, 4, 1, 4, 1>"}.get((name, tuple(shape)))
+    return table[key]["hbm_bytes"] if key in table else None
+
+
 def kernel_model(name, shape):
-    """Algorithmic work of one launch (DESIGN.md 'Kernels'): (bound, flops, bytes)."""
+    """Algorithmic work of one launch (DESIGN.md 'Kernels'): (bound, flops, bytes).  The binding roof is chosen by
+    arithmetic intensity against the fp32-MFMA / HBM ridge; gather / streaming kernels are HBM-bound."""
+    bound, flops, byts = _kernel_model(name, shape)
+    if flops and byts:
+        bound = "mfma" if flops / byts > RIDGE else "hbm"
+    return bound, flops, byts
+
+
+def _kernel_model(name, shape):
     if name.startswith("kan_conv2d"):
         B, Cin, Cout, H, W = shape
         flops = 2.0 * B * H * W * (81 * Cin) * Cout           # implicit GEMM, K = 9 taps x 9 basis x Cin
@@ -190,7 +214,7 @@ def main():
                     "frac": d["TFLOP/s"] / PEAK_F32_MFMA_TFLOPS}
         else:
             roof = {"bound": "hbm", "achieved": d["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["GB/s"] / PEAK_HBM_GBS}
-        roof.update({"traffic": None, "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_flops": flops,
+        roof.update({"traffic": pmc_traffic(name, shape), "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_flops": flops,
                      "algorithmic_bytes": byts, "hbm_GBps_on_algorithmic_bytes": d["GB/s"]})
         out["roofline"] = roof
         out["kernels"] = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
