@@ -87,9 +87,11 @@ def _kernel_model(name, shape):
     return "hbm", 0.0, 0.0
 
 
-def cpu_baseline(T, H, steps=3):
-    """CPU oracle (oracle/model.py = the reference's op sequence) fwd + MSE + bwd + AdamW, B=2."""
+def cpu_baseline(T, H, steps=3, loss="hybrid"):
+    """CPU oracle (oracle/model.py = the reference's op sequence) fwd + loss + bwd + AdamW, B=2."""
+    from oracle.loss import hybrid_loss
     from oracle.model import KM_UNetV3 as Oracle
+    crit = hybrid_loss if loss == "hybrid" else torch.nn.functional.mse_loss
     torch.manual_seed(0)
     # one GPU's host share on the box is 16 cores; more threads only add oversubscription on these
     # small tensors (measured: 128 threads = 14.6 s/step, slower than 8 threads in the build container)
@@ -103,15 +105,15 @@ def cpu_baseline(T, H, steps=3):
         t0 = time.perf_counter()
         d = data.squeeze(2)
         opt.zero_grad()
-        loss = torch.nn.functional.mse_loss(m(d[:, :5]), d[:, 5:])
-        loss.backward()
+        lv = crit(m(d[:, :5]), d[:, 5:])
+        lv.backward()
         opt.step()
         if i:
             times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
     return {"value": B * T / t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle KM_UNetV3 train step (fwd+MSE+bwd+AdamW) at B=%d,T=%d,%dx%d fp32, median of %d steps after 1 warm-up, %.2f s/step"
-                      % (B, T, H, H, steps, t)}
+            "sample": "oracle KM_UNetV3 train step (fwd+%s loss+bwd+AdamW) at B=%d,T=%d,%dx%d fp32, median of %d steps after 1 warm-up, %.2f s/step"
+                      % (loss, B, T, H, H, steps, t)}
 
 
 def main():
@@ -123,6 +125,8 @@ def main():
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss", choices=("hybrid", "mse"), default="hybrid",
+                    help="hybrid = the reference's HybridLoss (train_shanghai.py:298-325), the default; mse = plain MSE")
     ap.add_argument("--no-graph", action="store_true", help="run eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
@@ -155,7 +159,7 @@ def main():
     model = km_unet_amd.KM_UNetV3(num_classes=T - 5).to(dev).train()
     torch.manual_seed(1234 + rank)            # per-rank data shard and DropPath stream
     data = torch.rand(B, T, 1, H, H, device=dev)
-    eager = TrainStep(model, data, capturable=not args.no_graph)
+    eager = TrainStep(model, data, capturable=not args.no_graph, loss=args.loss)
     step = eager if args.no_graph else GraphedTrainStep(eager, data)
 
     def sync():
@@ -184,8 +188,8 @@ def main():
         out = {"metric": "train frames/sec (BxT) KM-UNetV3_SH 128x128 T=10", "value": world * B * T / (dt / args.steps),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "KM_UNetV3_SH(num_classes=%d) train step (fwd + MSE + bwd + grad all-reduce + AdamW), "
-                                      "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, B, T, H, H),
+               "config": {"workload": "KM_UNetV3_SH(num_classes=%d) train step (fwd + %s loss + bwd + grad all-reduce + AdamW), "
+                                      "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, args.loss, B, T, H, H),
                           "global_batch": world * B, "frames_per_sample": T, "parallelism": "dp%d" % world},
                "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay"}
 
@@ -225,7 +229,7 @@ def main():
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, H)
+            out["cpu_baseline"] = cpu_baseline(T, H, loss=args.loss)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

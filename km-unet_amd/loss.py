@@ -1,0 +1,70 @@
+"""HybridLoss of the reference training loop (train_shanghai.py:298-325) and the CSI / POD / FAR / HSS
+contingency scores of its evaluator (metrics.py:45-47,105-114,220-288), as device-side PyTorch-ROCm ops
+(these are callers either side of the hot path, SURVEY.md 8f -- not hand-written kernels).
+
+SSIM: torchmetrics' StructuralSimilarityIndexMeasure(data_range=1.0) is third-party and not available here; its
+published defaults are restated (gaussian 11x11, sigma 1.5, k1 .01, k2 .03, reflect pad 5, border cropped).  The
+11x11 window is applied separably (two 1-D depthwise passes), which is the same filter.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class HybridLoss(nn.Module):
+    def __init__(self, alpha=0.7, kernel_size=11, sigma=1.5):
+        super().__init__()
+        self.alpha, self.k, self.pad = alpha, kernel_size, (kernel_size - 1) // 2
+        dist = torch.arange((1 - kernel_size) / 2, (1 + kernel_size) / 2, 1)
+        g = torch.exp(-((dist / sigma) ** 2) / 2)
+        self.register_buffer("gauss", g / g.sum(), persistent=False)
+
+    def _filter(self, x):
+        c = x.shape[1]
+        gh = self.gauss.view(1, 1, self.k, 1).expand(c, 1, self.k, 1)
+        gw = self.gauss.view(1, 1, 1, self.k).expand(c, 1, 1, self.k)
+        return F.conv2d(F.conv2d(x, gh, groups=c), gw, groups=c)
+
+    def ssim(self, p, t):
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        pad = self.pad
+        p = F.pad(p, (pad, pad, pad, pad), mode="reflect")
+        t = F.pad(t, (pad, pad, pad, pad), mode="reflect")
+        b = p.shape[0]
+        mu_p, mu_t, e_pp, e_tt, e_pt = self._filter(torch.cat((p, t, p * p, t * t, p * t))).split(b)
+        s_pp, s_tt, s_pt = e_pp - mu_p * mu_p, e_tt - mu_t * mu_t, e_pt - mu_p * mu_t
+        smap = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (s_pp + s_tt + c2))
+        smap = smap[..., pad:-pad, pad:-pad]
+        return smap.reshape(b, -1).mean(-1).mean()
+
+    def forward(self, pred, target):
+        d = pred - target
+        sq = d * d
+        mse = sq.mean()
+        weighted = (sq * torch.exp(target * 2)).mean()
+        tmin, tmax = torch.aminmax(target.detach())
+        pmin, pmax = torch.aminmax(pred.detach())
+        tn = (target - tmin) / (tmax - tmin + 1e-8)
+        pn = (pred - pmin) / (pmax - pmin + 1e-8)
+        return self.alpha * (0.55 * mse + 0.45 * weighted) + (1 - self.alpha) * (1 - self.ssim(pn, tn))
+
+
+THRESHOLDS = (20, 30, 35, 40)
+
+
+def contingency_scores(pred, target, thresholds=THRESHOLDS, scale=90):
+    """-> {threshold: {csi, pod, far, hss}} from pooled TP/FN/FP/TN counts, computed on the device; the uint16
+    truncation of clip(x,0,1)*scale is the reference's (metrics.py:45-47)."""
+    p = (pred.detach().clamp(0, 1) * scale).to(torch.int32)
+    t = (target.detach().clamp(0, 1) * scale).to(torch.int32)
+    out = {}
+    for th in thresholds:
+        pb, tb = p >= th, t >= th
+        tp = (pb & tb).sum().item()
+        fn = (~pb & tb).sum().item()
+        fp = (pb & ~tb).sum().item()
+        tn = (~pb & ~tb).sum().item()
+        div = lambda a, b: float(a) / b if b else float("nan")
+        out[th] = {"csi": div(tp, tp + fp + fn), "pod": div(tp, tp + fn), "far": div(fp, tp + fp),
+                   "hss": div(2 * (tp * tn - fp * fn), fp ** 2 + fn ** 2 + 2 * tp * tn + (fp + fn) * (tp + tn))}
+    return out

@@ -229,12 +229,13 @@ class EfficientViMBlock(nn.Module):
             x = torch.lerp(x, y, a[1])
             x = torch.lerp(x, self.dwconv2(x), a[2])
             return torch.lerp(x, self.ffn(x), a[3])
-        x = ops.bn_blend(self.dwconv1.conv_only(x), x, self.dwconv1.norm, self.alpha, 0)
+        a0, a1, a2, a3 = self.alpha.unbind(0)     # one stack() in backward instead of 4 x (zeros + add)
+        x = ops.bn_blend(self.dwconv1.conv_only(x), x, self.dwconv1.norm, a0)
         y, _ = self.mixer(self.norm(x.flatten(2)))
-        x = ops.bn_blend(y, x, None, self.alpha, 1)
-        x = ops.bn_blend(self.dwconv2.conv_only(x), x, self.dwconv2.norm, self.alpha, 2)
+        x = ops.bn_blend(y, x, None, a1)
+        x = ops.bn_blend(self.dwconv2.conv_only(x), x, self.dwconv2.norm, a2)
         h = self.ffn.fc1(x)
-        return ops.bn_blend(self.ffn.fc2.conv_only(h), x, self.ffn.fc2.norm, self.alpha, 3)
+        return ops.bn_blend(self.ffn.fc2.conv_only(h), x, self.ffn.fc2.norm, a3)
 
 
 # ------------------------------------------------------------------ DySample (K3)

@@ -197,6 +197,7 @@ class HsmssdFn(torch.autograd.Function):
                              _ptr(w_out), _ptr(D), _ptr(y), _ptr(h), _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, stage, st),
                        "kmu_hsmssd_fwd_stage")
         ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
+        ctx.set_materialize_grads(False)      # EfficientViMBlock drops h: no zero tensor for its gradient
         ctx.dims = (B, C, N, Hs)
         ctx.A_shape = A.shape
         return y, h
@@ -369,15 +370,16 @@ class BnBlendFn(torch.autograd.Function):
     (EfficientViMBlock.forward, efficient_vim_init.py:81-97, with ConvLayer2D's norm/act, vim_utils_init.py:62-89)."""
 
     @staticmethod
-    def forward(ctx, t, x, gamma, beta, alpha, row, running_mean, running_var, momentum, eps, relu, training):
+    def forward(ctx, t, x, gamma, beta, a_row, running_mean, running_var, momentum, eps, relu, training):
         lib = _lib.load()
         t = _f32c(t, "t")
         x = _f32c(x, "x") if x is not None else None
         B, C = t.shape[:2]
         HW = t.numel() // (B * C)
         dev = t.device
-        has_bn, has_blend = gamma is not None, alpha is not None
-        a_row = alpha[row] if has_blend else None
+        has_bn, has_blend = gamma is not None, a_row is not None
+        if has_blend:
+            a_row = _f32c(a_row, "alpha row")
         out = torch.empty_like(t)
         S = lib.kmu_bn_blend_splits(B, HW)
         stats = torch.empty(C, 2, device=dev, dtype=torch.float32) if has_bn else None
@@ -385,41 +387,40 @@ class BnBlendFn(torch.autograd.Function):
         _lib.check(_call(("bn_blend_fwd", (B, C, HW)), lib.kmu_bn_blend_fwd, _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row),
                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), int(relu), int(training), _ptr(out),
                          _ptr(stats), _ptr(ws), B, C, HW, _stream()), "kmu_bn_blend_fwd")
-        ctx.save_for_backward(t, x, gamma, beta, alpha, stats)
-        ctx.cfg = (row, int(relu), int(training), B, C, HW, S)
+        ctx.save_for_backward(t, x, gamma, beta, a_row, stats)
+        ctx.cfg = (int(relu), int(training), B, C, HW, S)
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        t, x, gamma, beta, alpha, stats = ctx.saved_tensors
-        row, relu, training, B, C, HW, S = ctx.cfg
+        t, x, gamma, beta, a_row, stats = ctx.saved_tensors
+        relu, training, B, C, HW, S = ctx.cfg
         g = _f32c(g, "grad")
         dev = t.device
-        has_bn, has_blend = gamma is not None, alpha is not None
-        a_row = alpha[row] if has_blend else None
+        has_bn, has_blend = gamma is not None, a_row is not None
         dt = torch.empty_like(t)
         dx = torch.empty_like(t) if has_blend else None
         dg = torch.empty(C, device=dev, dtype=torch.float32) if has_bn else None
         db = torch.empty(C, device=dev, dtype=torch.float32) if has_bn else None
-        da = torch.zeros_like(alpha) if has_blend else None
+        da = torch.empty(C, device=dev, dtype=torch.float32) if has_blend else None
         ws = torch.empty(C * S * 3, device=dev, dtype=torch.float32)
         _lib.check(_call(("bn_blend_bwd", (B, C, HW)), lib.kmu_bn_blend_bwd, _ptr(g), _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta),
-                         _ptr(a_row), _ptr(stats), relu, training, _ptr(dt), _ptr(dx), _ptr(dg), _ptr(db),
-                         _ptr(da[row]) if has_blend else None, _ptr(ws), B, C, HW, _stream()), "kmu_bn_blend_bwd")
-        return dt, dx, dg, db, da, None, None, None, None, None, None, None
+                         _ptr(a_row), _ptr(stats), relu, training, _ptr(dt), _ptr(dx), _ptr(dg), _ptr(db), _ptr(da), _ptr(ws),
+                         B, C, HW, _stream()), "kmu_bn_blend_bwd")
+        return dt, dx, dg, db, da, None, None, None, None, None, None
 
 
 def bn_blend(t, x=None, bn=None, alpha=None, row=0, relu=False):
-    """t: conv output; x: blend partner (or None); bn: an nn.BatchNorm2d (or None); alpha: the raw [4, C]
-    layer-scale parameter (or None)."""
+    """t: conv output; x: blend partner (or None); bn: an nn.BatchNorm2d (or None); alpha: the RAW layer-scale --
+    either the [4, C] parameter (row selects) or an already selected [C] row (or None for no blend)."""
+    a_row = None if alpha is None else (alpha if alpha.dim() == 1 else alpha[row])
     if bn is None:
-        return BnBlendFn.apply(t, x, None, None, alpha, row, None, None, 0.0, 0.0, relu, False)
+        return BnBlendFn.apply(t, x, None, None, a_row, None, None, 0.0, 0.0, relu, False)
     training = bn.training
     if training and bn.track_running_stats:
         bn.num_batches_tracked.add_(1)
-    return BnBlendFn.apply(t, x, bn.weight, bn.bias, alpha, row, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu,
-                           training)
+    return BnBlendFn.apply(t, x, bn.weight, bn.bias, a_row, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, training)
 
 
 # ------------------------------------------------------------------------------------------ sigmoid(q*k)*v

@@ -2,13 +2,13 @@
 data [B,T,1,H,W] -> squeeze(2) -> input = data[:, :5], target = data[:, 5:] -> model -> loss ->
 backward -> optimizer step.  AdamW(lr 1e-3, weight_decay 0.05) as train_shanghai.py:342.
 
-Loss: plain MSE for now; the reference's HybridLoss (train_shanghai.py:298-325) adds a weighted-MSE and
-a torchmetrics SSIM term (third-party, restated in a later round -- SURVEY 8f-1).
+Loss: the reference's HybridLoss (train_shanghai.py:298-325; km-unet_amd/loss.py) by default, plain MSE on request.
 """
 import torch
 import torch.nn.functional as F
 
 from .dp import DataParallel, live_parameters
+from .loss import HybridLoss
 
 
 def split_frames(data):
@@ -17,8 +17,10 @@ def split_frames(data):
 
 
 class TrainStep:
-    def __init__(self, model, example_data, lr=1e-3, weight_decay=0.05, process_group=None, capturable=False):
+    def __init__(self, model, example_data, lr=1e-3, weight_decay=0.05, process_group=None, capturable=False,
+                 loss="hybrid"):
         self.model = model
+        self.criterion = HybridLoss().to(example_data.device) if loss == "hybrid" else F.mse_loss
         inp, _ = split_frames(example_data)
         live = live_parameters(model, inp)
         self.dp = DataParallel(model, live, process_group)
@@ -31,7 +33,7 @@ class TrainStep:
         inp, tgt = split_frames(data)
         self.dp.zero_grad()
         out = self.model(inp)
-        loss = F.mse_loss(out, tgt)
+        loss = self.criterion(out, tgt)
         loss.backward()
         return loss
 

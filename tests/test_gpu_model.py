@@ -89,3 +89,28 @@ def test_model_matches_oracle_at_128():
     dcsi = max(abs(so[t]["csi"] - sp[t]["csi"]) for t in so if so[t]["csi"] == so[t]["csi"])
     print("  [model128] y=%.2e  max|dCSI|=%.2e" % (e, dcsi))
     assert e < TOL and dcsi < 1e-3
+
+
+def test_hybrid_loss_and_csi_vs_oracle():
+    """HybridLoss (train_shanghai.py:298-325; SSIM = torchmetrics restated => unpinned) and the CSI/POD/FAR/HSS
+    scores (metrics.py) on the device vs the CPU oracle restatements."""
+    import km_unet_amd
+    from km_unet_amd.loss import HybridLoss, contingency_scores
+    from oracle import csi as ocsi
+    from oracle.loss import hybrid_loss
+    gen = torch.Generator().manual_seed(21)
+    pred = torch.rand(2, 5, 64, 64, generator=gen).requires_grad_(True)
+    tgt = torch.rand(2, 5, 64, 64, generator=gen)
+    lo = hybrid_loss(pred, tgt)
+    lo.backward()
+    pd = pred.detach().cuda().requires_grad_(True)
+    lg = HybridLoss().cuda()(pd, tgt.cuda())
+    lg.backward()
+    print("  [hybrid_loss] value %.2e grad %.2e" % (abs(lg.item() - lo.item()) / abs(lo.item()), rel_err(pd.grad, pred.grad)))
+    assert abs(lg.item() - lo.item()) < 1e-5 * abs(lo.item()) + 1e-7 and rel_err(pd.grad, pred.grad) < TOL
+    so = ocsi.scores(pred.detach().numpy(), tgt.numpy())
+    sg = contingency_scores(pd, tgt.cuda())
+    for th in so:
+        for k in so[th]:
+            a, b = so[th][k], sg[th][k]
+            assert (a != a and b != b) or abs(a - b) < 1e-12, (th, k, a, b)
