@@ -32,7 +32,8 @@ class HybridLoss(nn.Module):
         t = F.pad(t, (pad, pad, pad, pad), mode="reflect")
         b = p.shape[0]
         mu_p, mu_t, e_pp, e_tt, e_pt = self._filter(torch.cat((p, t, p * p, t * t, p * t))).split(b)
-        s_pp, s_tt, s_pt = e_pp - mu_p * mu_p, e_tt - mu_t * mu_t, e_pt - mu_p * mu_t
+        s_pp, s_tt = (e_pp - mu_p * mu_p).clamp(min=0.0), (e_tt - mu_t * mu_t).clamp(min=0.0)   # variances: non-negative
+        s_pt = e_pt - mu_p * mu_t
         smap = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (s_pp + s_tt + c2))
         smap = smap[..., pad:-pad, pad:-pad]
         return smap.reshape(b, -1).mean(-1).mean()

@@ -7,7 +7,8 @@ with pred_n / target_n min-max normalised by their own (detached) extrema (+1e-8
 SSIM is torchmetrics.image.StructuralSimilarityIndexMeasure(data_range=1.0) (torchmetrics 1.5.2,
 requirements.txt:82) -- third-party, not vendored in the reference and not installed here => restated from its
 published defaults, PARITY UNPINNED: gaussian 11x11 window, sigma 1.5, k1 0.01, k2 0.03, inputs reflect-padded by
-5, per-channel (depthwise) filtering, the padded border cropped from the SSIM map, mean over (C,H,W) then batch.
+5, per-channel (depthwise) filtering, both variances clamped at 0, the padded border cropped from the SSIM map,
+mean over (C,H,W) then batch.
 """
 import torch
 import torch.nn.functional as F
@@ -30,7 +31,8 @@ def ssim(pred, target, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.
     stack = torch.cat((p, t, p * p, t * t, p * t))
     out = F.conv2d(stack, win, groups=c)
     mu_p, mu_t, e_pp, e_tt, e_pt = out.split(pred.shape[0])
-    s_pp, s_tt, s_pt = e_pp - mu_p * mu_p, e_tt - mu_t * mu_t, e_pt - mu_p * mu_t
+    s_pp, s_tt = (e_pp - mu_p * mu_p).clamp(min=0.0), (e_tt - mu_t * mu_t).clamp(min=0.0)   # variances: non-negative
+    s_pt = e_pt - mu_p * mu_t
     smap = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (s_pp + s_tt + c2))
     smap = smap[..., pad:-pad, pad:-pad]
     return smap.reshape(smap.shape[0], -1).mean(-1).mean()
