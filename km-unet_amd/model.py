@@ -18,6 +18,19 @@ from . import ops
 from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1, group_norm
 
 
+import os as _os
+
+_BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") != "0"
+_SIDE = {}
+
+
+def _side_streams(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _SIDE[key]
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm 0.9.16 semantics: mask ~ Bernoulli(1-p) / (1-p), train only)."""
 
@@ -129,8 +142,28 @@ class EnhancedViMBlock(nn.Module):
         self.norm = TripleNorm(dim)
         self.drop_path = DropPath(drop_path) if drop_path > 0 else nn.Identity()
 
+    def _branches(self, x):
+        """The three direction branches are independent: fork them onto side HIP streams (parallel branches of the
+        captured hipGraph; autograd replays each branch's backward on the stream it ran on).  Their kernels at the
+        64x64 / 32x32 levels are far too small to fill 256 CUs one at a time."""
+        if not (x.is_cuda and _BRANCH_STREAMS):
+            return [self.height_block(x), self.width_block(x), self.channel_block(x)]
+        cur = torch.cuda.current_stream()
+        side = _side_streams(x.device)
+        ready = cur.record_event()
+        feats = [None, None, None]
+        feats[0] = self.height_block(x)
+        for i, (st, blk) in enumerate(zip(side, (self.width_block, self.channel_block)), start=1):
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                feats[i] = blk(x)
+        for st, f in zip(side, feats[1:]):
+            cur.wait_stream(st)
+            f.record_stream(cur)          # produced on a side stream, consumed (and later freed) on the main one
+        return feats
+
     def forward(self, x):
-        feats = [self.height_block(x), self.width_block(x), self.channel_block(x)]
+        feats = self._branches(x)
         g = self.fusion_gate(torch.cat(feats, dim=1))
         x = x + self.drop_path(g[:, 0:1] * feats[0] + g[:, 1:2] * feats[1] + g[:, 2:3] * feats[2])
         f = conv1x1(F.gelu(conv1x1(self.norm(x), self.ffn[0])), self.ffn[2])
