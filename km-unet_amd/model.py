@@ -20,7 +20,7 @@ from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingMod
 
 import os as _os
 
-_BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") != "0"
+_BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "0") == "1"   # measured slower (34.1 vs 30.6 ms/step): opt-in only
 _SIDE = {}
 
 
