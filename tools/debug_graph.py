@@ -6,22 +6,6 @@ import km_unet_amd
 from km_unet_amd.loss import HybridLoss
 from km_unet_amd.train import TrainStep, GraphedTrainStep
 dev = "cuda"
-# (1) HybridLoss alone: eager vs captured
-torch.manual_seed(0)
-crit = HybridLoss().to(dev)
-pred = torch.rand(8, 5, 128, 128, device=dev, requires_grad=True); tgt = torch.rand(8, 5, 128, 128, device=dev)
-le = crit(pred, tgt); le.backward(); ge = pred.grad.clone(); pred.grad = None
-s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(2):
-        l = crit(pred, tgt); l.backward(); pred.grad = None
-torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-pred.grad = torch.zeros_like(pred)
-with torch.cuda.graph(g):
-    lg = crit(pred, tgt); lg.backward()
-pred.grad.zero_(); g.replay(); torch.cuda.synchronize()
-print("HybridLoss alone: eager %.6f graph %.6f  grad diff %.2e" % (le.item(), lg.item(), (pred.grad - ge).abs().max().item()))
 # (2) whole step, replay-by-replay
 for loss_kind in ("hybrid", "mse"):
     torch.manual_seed(0)
