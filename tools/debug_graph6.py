@@ -37,6 +37,9 @@ def run(mode, droppath):
         vals.append(gs(data).item())
     print("%-8s droppath=%d " % (mode, droppath), " ".join("%.5f" % v for v in vals), flush=True)
 
-for mode in ("mse", "wmse", "minmax", "full"):
-    for dp in (0, 1):
-        run(mode, dp)
+if len(sys.argv) > 1:
+    run(sys.argv[1], int(sys.argv[2]))
+else:
+    for mode in ("mse", "wmse", "minmax", "full"):
+        for dp in (0, 1):
+            run(mode, dp)
