@@ -24,8 +24,11 @@ import sys
 import time
 import warnings
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")       # km-unet_amd/__init__.py: numerics policy
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")    # km-unet_amd/__init__.py: hipGraph replay policy
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -168,6 +171,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    loss = step(data)                        # one extra untimed step: reference point of the sanity check below
+    loss_ref = loss.item()
     for _ in range(args.warmup):
         loss = step(data)
     sync()
@@ -181,6 +186,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     final_loss = loss.item()
+    # the same batch is fitted over and over, so the loss can only drift down; a jump means the replayed step no
+    # longer computes the step (see km-unet_amd/__init__.py on DEBUG_CLR_GRAPH_PACKET_CAPTURE) -> no number at all
+    if not (final_loss == final_loss and final_loss <= 1.5 * loss_ref + 1e-3):
+        raise RuntimeError("bench: loss went %.5g -> %.5g over the timed steps; the measured step is not a valid "
+                           "training step" % (loss_ref, final_loss))
 
     out = None
     if rank == 0:
@@ -191,7 +201,7 @@ def main():
                "config": {"workload": "KM_UNetV3_SH(num_classes=%d) train step (fwd + %s loss + bwd + grad all-reduce + AdamW), "
                                       "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, args.loss, B, T, H, H),
                           "global_batch": world * B, "frames_per_sample": T, "parallelism": "dp%d" % world},
-               "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay"}
+               "loss_first": loss_ref, "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay"}
 
     # ---- roofline leg: extra instrumented steps, HIP events around every C-ABI launch ----------
     # (every rank runs them -- a step contains the gradient all-reduce -- only rank 0 records and reports)
