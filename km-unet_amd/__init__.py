@@ -13,7 +13,7 @@ _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
 
 # hipGraph policy: the HIP runtime's AQL packet capture for graphs (default on in ROCm 7) replays the ~5k-node
 # train-step graph wrongly once the host has synchronised the stream between two replays -- reductions inside
-# the captured loss return garbage from then on (measured on MI355X, tools/debug_graph6.py: 0.4332 -> 216.4;
+# the captured loss return garbage from then on (measured on MI355X, tools/repro_graph_replay_sync.py: 0.4332 -> 216.4;
 # correct with the capture path off, every other runtime knob made no difference).  Read at HIP runtime
 # initialisation, so it has to be in the environment before the first HIP call of the process.
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
