@@ -202,6 +202,24 @@ int kmu_qkv_gate_fwd(const float* qkv, float* out, int B, int C, int HW, kmu_str
 int kmu_qkv_gate_bwd(const float* qkv, const float* gout, float* dqkv, int B, int C, int HW, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Pointwise (1x1) convolution, NCHW fp32: EnhancedViMBlock.ffn (KM_UNetV3_SH.py:120-124), the EfficientViM FFN's
+ * two ConvLayer2D 1x1 (vim_block_init/vim_utils_init.py:62-89), DirectionAttention.qkv (KM_UNetV3_SH.py:221), the
+ * 'channel' projection (:174), StableHybridKANConv.residual (:59).  x [B,Ci,P], w [Co,Ci], bias [Co] or NULL.
+ *   fwd        y  = W * act(x) + bias            act_in = 0: identity, 1: exact (erf) GELU applied to x on load
+ *   bwd_input  dx = (W^T * gy) . act'(x_pre)     x_pre = the forward's x, only read when act_in
+ *   bwd_weight dW = sum_{b,p} gy * act(x)^T, dbias = sum_{b,p} gy (dbias may be NULL); deterministic two-stage
+ *              reduction through ws (kmu_pwconv_bwd_weight_ws_bytes).
+ * Ci, Co positive multiples of 16 and <= 256; P = H*W a multiple of 64.
+ * ------------------------------------------------------------------------------------ */
+int kmu_pwconv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int P, int act_in,
+                   kmu_stream_t stream);
+int kmu_pwconv_bwd_input(const float* gy, const float* w, const float* x_pre, float* dx, int B, int Ci, int Co, int P,
+                         int act_in, kmu_stream_t stream);
+size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P);
+int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci,
+                          int Co, int P, int act_in, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * GroupNorm(G, C) over [B,C,HW]: StableHybridKANConv.pre_norm (KM_UNetV3_SH.py:57,73), TripleNorm.norm_h/w
  * (:271-273), MultiScaleFusion (:294), KM_UNetV3.output_norm (:448,516).  stats [B,G,2] = (mean, rstd);
  * ws: [B*C*S*2] floats, S = kmu_group_norm_splits(HW); d_gamma/d_beta leave as [B,C] partials.

@@ -26,6 +26,7 @@ SOURCES = [
     ("bn_blend.hip", []),
     ("qkv_gate.hip", []),
     ("group_norm.hip", []),
+    ("pwconv.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

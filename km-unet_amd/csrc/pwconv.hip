@@ -1,0 +1,332 @@
+// Pointwise (1x1) convolution over NCHW fp32 -- the FFNs (KM_UNetV3_SH.py:120-124, vim_block_init/
+// efficient_vim_init.py FFN = two ConvLayer2D 1x1, vim_utils_init.py:62-89), the qkv projection (:221), the
+// 'channel' direction projection (:174) and StableHybridKANConv.residual (:59).
+//
+//   forward      y[b,co,p]  = sum_ci W[co,ci] * act(x[b,ci,p]) + bias[co]            act = identity | exact GELU
+//   bwd_input    dx[b,ci,p] = (sum_co W[co,ci] * gy[b,co,p]) * act'(x[b,ci,p])
+//   bwd_weight   dW[co,ci]  = sum_{b,p} gy[b,co,p] * act(x[b,ci,p]),   dbias[co] = sum_{b,p} gy[b,co,p]
+//
+// With 16..256 channels these are HBM-bound (Ci*Co/(2(Ci+Co)) = 6..26 FLOP/B against a ridge of 19.7): the job
+// is to read x / gy once with wide loads and write y once, with bias, GELU, GELU' and the bias gradient folded in
+// (stock path: bmm + bias add + gelu, and for backward 2 bmm + a batch sum + a bias reduction, 11 launches).
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32).  Both the 16 "M" rows and the 4 "K" slots of an MFMA are
+// free permutations as long as A, B and D agree, which lets every lane issue 16-byte loads straight from NCHW:
+//   fwd / bwd_input : M = pixels, N = out channels, K = in channels.  Lane (m = l%16, q = l/16) loads ONE float4
+//     x[ch(c,s,q)][p0 + 4m .. 4m+3], ch = 16c + 4q + s: its 4 components are the A operands of 4 M-tiles t
+//     (pixel(m,t) = p0 + 4m + t).  A D tile then holds, per lane, pixels p0 + 16q + 4i + t -> with the 4 tiles
+//     side by side each lane owns 16 consecutive pixels of one output channel: 4 float4 stores.
+//   bwd_weight      : M = out channels, N = in channels, K = pixels.  Lane (r = l%16, q) loads 2 float4 = pixels
+//     p0 + 8q .. 8q+7 of row r of each gy / x tile; K-step s pairs component s of both (pixel p0 + 8q + s).
+// Weights are staged once per workgroup in LDS as wl[k][n] (row stride = 16 mod 32 words: conflict-free
+// ds_read_b32 B fragments).  bwd_weight needs no LDS: every wave dumps its accumulators as a slab and
+// pw_wgrad_reduce_kernel adds the slabs in a fixed order (deterministic, no atomics).
+#include "common.h"
+
+using kmu::floatx4;
+
+namespace {
+
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+    return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+}
+
+__host__ __device__ inline int lds_stride(int nt) { return (16 * nt) % 32 == 16 ? 16 * nt : 16 * nt + 16; }
+
+// ---------------------------------------------------------------------------------------- fwd / bwd_input
+// grid.x = B * ceil(P / 256), grid.y = N / (16 NT); 4 waves x 64 pixels.  w(n, k) = w[n * w_sn + k * w_sk].
+template <int NT>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w, long w_sn,
+                                                      long w_sk, const float* __restrict__ bias,
+                                                      const float* __restrict__ mul_pre, float* __restrict__ y, int K, int N,
+                                                      int P, int act_in) {
+    extern __shared__ float wl[];
+    constexpr int S = (16 * NT) % 32 == 16 ? 16 * NT : 16 * NT + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int bpp = (P + 255) / 256;
+    const int b = blockIdx.x / bpp, p0 = (blockIdx.x % bpp) * 256 + wave * 64;
+    const int n0 = blockIdx.y * 16 * NT;
+
+    // stage W[n0 .. n0+16NT) x [0, K) -> wl[k][n]
+    if (w_sk == 1) {
+        for (int e = tid; e < 16 * NT * K; e += 256) {
+            const int n = e / K, k = e - n * K;
+            wl[k * S + n] = w[(long)(n0 + n) * w_sn + k];
+        }
+    } else {
+        for (int e = tid; e < 16 * NT * K; e += 256) {
+            const int k = e / (16 * NT), n = e - k * 16 * NT;
+            wl[k * S + n] = w[(long)(n0 + n) * w_sn + (long)k * w_sk];
+        }
+    }
+    __syncthreads();
+    if (p0 >= P) return;
+
+    const float* xb = x + (size_t)b * K * P + p0 + 4 * m;
+    floatx4 acc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[nt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    floatx4 xv[4], xn[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xv[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(4 * q + s) * P);
+    const int nchunk = K / 16;
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xn[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(16 * (c + 1) + 4 * q + s) * P);
+        }
+        if (act_in) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xv[s][t] = gelu_f(xv[s][t]);
+        }
+        const float* wrow = wl + (16 * c + 4 * q) * S + m;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = wrow[s * S + 16 * nt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s][t], bf[nt], acc[nt][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xv[s] = xn[s];
+    }
+
+    // epilogue: lane owns channel n0 + 16nt + m, pixels p0 + 16q + 4i + t
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + 16 * nt + m;
+        const float bv = bias ? bias[n] : 0.f;
+        const size_t off = ((size_t)b * N + n) * P + p0 + 16 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            floatx4 o = {acc[nt][0][i] + bv, acc[nt][1][i] + bv, acc[nt][2][i] + bv, acc[nt][3][i] + bv};
+            if (mul_pre) {
+                const floatx4 z = *reinterpret_cast<const floatx4*>(mul_pre + off + 4 * i);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] *= gelu_grad_f(z[t]);
+            }
+            *reinterpret_cast<floatx4*>(y + off + 4 * i) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- bwd_weight
+// grid.x = G pixel groups, grid.y = (Co/16MT) * (Ci/16NT) slice pairs; 4 waves, each walks 32-pixel chunks
+// (chunk id = (g*4 + wave) + j * 4G) and dumps its accumulators to slab[sp][g*4+wave][mt][nt][lane] (float4).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       float* __restrict__ slab, float* __restrict__ bslab, int Ci, int Co,
+                                                       int P, int nchunks, int act_in) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nsl_i = Ci / (16 * NT);
+    const int sp = blockIdx.y, co0 = (sp / nsl_i) * 16 * MT, ci0 = (sp % nsl_i) * 16 * NT;
+    const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int cpp = P / 32;   // chunks per sample
+
+    floatx4 acc[MT][NT];
+    float bs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        bs[mt] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int ch = gw; ch < nchunks; ch += nw) {
+        const int b = ch / cpp, p0 = (ch - b * cpp) * 32 + 8 * q;
+        floatx4 a[MT][2], bx[NT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float* g = gy + ((size_t)b * Co + co0 + 16 * mt + r) * P + p0;
+            a[mt][0] = *reinterpret_cast<const floatx4*>(g);
+            a[mt][1] = *reinterpret_cast<const floatx4*>(g + 4);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float* xp = x + ((size_t)b * Ci + ci0 + 16 * nt + r) * P + p0;
+            bx[nt][0] = *reinterpret_cast<const floatx4*>(xp);
+            bx[nt][1] = *reinterpret_cast<const floatx4*>(xp + 4);
+        }
+        if (act_in) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) bx[nt][s >> 2][s & 3] = gelu_f(bx[nt][s >> 2][s & 3]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) bs[mt] += a[mt][s >> 2][s & 3];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s >> 2][s & 3], bx[nt][s >> 2][s & 3], acc[mt][nt], 0, 0, 0);
+    }
+    float* out = slab + (((size_t)sp * nw + gw) * MT * NT) * 256 + lane * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<floatx4*>(out + (mt * NT + nt) * 256) = acc[mt][nt];
+    if (bslab && sp % nsl_i == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float v = bs[mt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) bslab[((size_t)(sp / nsl_i) * nw + gw) * MT * 16 + mt * 16 + r] = v;
+        }
+    }
+}
+
+// one thread per accumulator float4: (sp, mt, nt, lane) -> rows co = co0 + 16mt + 4q + i, column ci = ci0 + 16nt + r
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                              float* __restrict__ dw, float* __restrict__ dbias, int Ci, int Co,
+                                                              int MT, int NT, int nw) {
+    const int per_sp = MT * NT * 64, nsl_i = Ci / (16 * NT), nsp = (Co / (16 * MT)) * nsl_i;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nsp * per_sp) {
+        const int sp = t / per_sp, e = t - sp * per_sp, tile = e >> 6, lane = e & 63;
+        const int mt = tile / NT, nt = tile - mt * NT, r = lane & 15, q = lane >> 4;
+        const float* src = slab + ((size_t)sp * nw * MT * NT + tile) * 256 + lane * 4;
+        floatx4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < nw; ++g) s += *reinterpret_cast<const floatx4*>(src + (size_t)g * MT * NT * 256);
+        const int co = (sp / nsl_i) * 16 * MT + 16 * mt + 4 * q, ci = (sp % nsl_i) * 16 * NT + 16 * nt + r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw[(size_t)(co + i) * Ci + ci] = s[i];
+    }
+    if (dbias && t < Co) {
+        const int so = t / (16 * MT), rem = t - so * 16 * MT;
+        const float* src = bslab + (size_t)so * nw * MT * 16 + rem;
+        float s = 0.f;
+        for (int g = 0; g < nw; ++g) s += src[(size_t)g * MT * 16];
+        dbias[t] = s;
+    }
+}
+
+inline int pick_tiles(int n16) { return n16 % 4 == 0 ? 4 : (n16 % 3 == 0 ? 3 : (n16 % 2 == 0 ? 2 : 1)); }
+
+struct WgradPlan {
+    int MT, NT, nsp, G, nw, nchunks;
+    size_t slab_floats, bslab_floats;
+};
+
+inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
+    WgradPlan pl;
+    pl.MT = pick_tiles(Co / 16);
+    pl.NT = pick_tiles(Ci / 16);
+    pl.nsp = (Co / (16 * pl.MT)) * (Ci / (16 * pl.NT));
+    pl.nchunks = B * (P / 32);
+    int G = pl.nchunks / 16;                       // >= 4 chunks per wave
+    G = G < 1 ? 1 : (G > 256 ? 256 : G);
+    while (G > 32 && (size_t)G * 4 * pl.MT * pl.NT * 1024 * pl.nsp > ((size_t)8 << 20)) G /= 2;   // keep the slabs <= 8 MB
+    pl.G = G;
+    pl.nw = 4 * G;
+    pl.slab_floats = (size_t)pl.nsp * pl.nw * pl.MT * pl.NT * 256;
+    pl.bslab_floats = (size_t)(Co / (16 * pl.MT)) * pl.nw * pl.MT * 16;
+    return pl;
+}
+
+template <int NT>
+int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y, int B,
+                int K, int N, int P, int act_in, hipStream_t st) {
+    const size_t lds = (size_t)K * lds_stride(NT) * sizeof(float);
+    KMU_MAX_LDS((pw_gemm_kernel<NT>), lds);
+    hipLaunchKernelGGL((pw_gemm_kernel<NT>), dim3(B * ((P + 255) / 256), N / (16 * NT)), dim3(256), lds, st, x, w, w_sn, w_sk, bias,
+                       mul_pre, y, K, N, P, act_in);
+    return 0;
+}
+
+int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y,
+         int B, int K, int N, int P, int act_in, hipStream_t st) {
+    KMU_REQUIRE(B > 0 && K > 0 && N > 0 && K % 16 == 0 && N % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16",
+                what, K, N);
+    KMU_REQUIRE(P > 0 && P % 64 == 0, "%s: H*W = %d must be a positive multiple of 64", what, P);
+    KMU_REQUIRE(K <= 256, "%s: %d contraction channels exceed the LDS weight tile (256)", what, K);
+    switch (pick_tiles(N / 16)) {
+        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
+        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
+        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
+        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
+    }
+    return kmu::launch_status(what);
+}
+
+template <int MT, int NT>
+void launch_wgrad(const WgradPlan& pl, const float* x, const float* gy, float* slab, float* bslab, int Ci, int Co, int P, int act_in,
+                  hipStream_t st) {
+    hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), dim3(pl.G, pl.nsp), dim3(256), 0, st, x, gy, slab, bslab, Ci, Co, P, pl.nchunks,
+                       act_in);
+}
+
+template <int MT>
+void launch_wgrad_nt(const WgradPlan& pl, const float* x, const float* gy, float* slab, float* bslab, int Ci, int Co, int P,
+                     int act_in, hipStream_t st) {
+    switch (pl.NT) {
+        case 4: launch_wgrad<MT, 4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        case 3: launch_wgrad<MT, 3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        case 2: launch_wgrad<MT, 2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        default: launch_wgrad<MT, 1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+    }
+}
+
+}  // namespace
+
+extern "C" int kmu_pwconv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int P, int act_in,
+                              kmu_stream_t stream) {
+    KMU_REQUIRE(x && w && y, "pwconv_fwd: null pointer");
+    return gemm("pwconv_fwd", x, w, Ci, 1, bias, nullptr, y, B, Ci, Co, P, act_in, (hipStream_t)stream);
+}
+
+extern "C" int kmu_pwconv_bwd_input(const float* gy, const float* w, const float* x_pre, float* dx, int B, int Ci, int Co, int P,
+                                    int act_in, kmu_stream_t stream) {
+    KMU_REQUIRE(gy && w && dx, "pwconv_bwd_input: null pointer");
+    KMU_REQUIRE(!act_in || x_pre, "pwconv_bwd_input: act_in needs the pre-activation input");
+    // dx[ci] = sum_co W[co][ci] gy[co]: the same contraction with K = Co, N = Ci and w(n = ci, k = co) = W[k*Ci + n]
+    return gemm("pwconv_bwd_input", gy, w, 1, Ci, nullptr, act_in ? x_pre : nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream);
+}
+
+extern "C" size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || P <= 0 || Ci % 16 || Co % 16 || P % 32) return 0;
+    const WgradPlan pl = wgrad_plan(B, Ci, Co, P);
+    return (pl.slab_floats + pl.bslab_floats) * sizeof(float);
+}
+
+extern "C" int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci,
+                                     int Co, int P, int act_in, kmu_stream_t stream) {
+    KMU_REQUIRE(x && gy && dw && ws, "pwconv_bwd_weight: null pointer");
+    KMU_REQUIRE(B > 0 && Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0,
+                "pwconv_bwd_weight: channels (%d -> %d) must be positive multiples of 16", Ci, Co);
+    KMU_REQUIRE(P > 0 && P % 32 == 0, "pwconv_bwd_weight: H*W = %d must be a positive multiple of 32", P);
+    const WgradPlan pl = wgrad_plan(B, Ci, Co, P);
+    KMU_REQUIRE(ws_bytes >= (pl.slab_floats + pl.bslab_floats) * sizeof(float), "pwconv_bwd_weight: workspace too small (%zu < %zu)",
+                ws_bytes, (pl.slab_floats + pl.bslab_floats) * sizeof(float));
+    float* slab = (float*)ws;
+    float* bslab = dbias ? slab + pl.slab_floats : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    switch (pl.MT) {
+        case 4: launch_wgrad_nt<4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        case 3: launch_wgrad_nt<3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        case 2: launch_wgrad_nt<2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        default: launch_wgrad_nt<1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+    }
+    int rc = kmu::launch_status("pwconv_bwd_weight");
+    if (rc) return rc;
+    const int threads = pl.nsp * pl.MT * pl.NT * 64;
+    const int need = threads > Co ? threads : Co;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((need + 255) / 256), dim3(256), 0, st, slab, bslab, dw, dbias, Ci, Co, pl.MT, pl.NT,
+                       pl.nw);
+    return kmu::launch_status("pwconv_bwd_weight(reduce)");
+}

@@ -166,7 +166,7 @@ class EnhancedViMBlock(nn.Module):
         feats = self._branches(x)
         g = self.fusion_gate(torch.cat(feats, dim=1))
         x = x + self.drop_path(g[:, 0:1] * feats[0] + g[:, 1:2] * feats[1] + g[:, 2:3] * feats[2])
-        f = conv1x1(F.gelu(conv1x1(self.norm(x), self.ffn[0])), self.ffn[2])
+        f = conv1x1(conv1x1(self.norm(x), self.ffn[0]), self.ffn[2], gelu_in=True)   # GELU folded into ffn[2]'s load
         return x + self.drop_path(f)
 
 

@@ -19,13 +19,19 @@ import os as _os
 _TORCH_GLUE = set(filter(None, _os.environ.get("KMU_GLUE_TORCH", "").split(",")))
 
 
-def conv1x1(x, conv):
-    """1x1 convolution of an nn.Conv2d's parameters as ONE strided-batched GEMM  W[Co,Ci] @ x[b][Ci, H*W].
-    (MIOpen serves NCHW 1x1 convs with im2col + batched transposes around a GEMM: 3-4 launches.)"""
+def conv1x1(x, conv, gelu_in=False):
+    """1x1 convolution of an nn.Conv2d's parameters, optionally of GELU(x): the HIP pointwise-conv kernels
+    (csrc/pwconv.hip: bias / GELU / GELU' / bias-gradient folded in) when the channel counts are multiples of 16,
+    else ONE strided-batched GEMM  W[Co,Ci] @ x[b][Ci, H*W]  (MIOpen serves NCHW 1x1 convs with im2col + batched
+    transposes around a GEMM: 3-4 launches)."""
     if "conv1x1" in _TORCH_GLUE:
-        return conv(x)
+        return conv(F.gelu(x) if gelu_in else x)
     b, ci, h, w = x.shape
     co = conv.weight.shape[0]
+    if "pwconv" not in _TORCH_GLUE and ops.pwconv_supported(ci, co, h * w):
+        return ops.pwconv(x, conv.weight, conv.bias, gelu_in)
+    if gelu_in:
+        x = F.gelu(x)
     y = torch.bmm(conv.weight.view(1, co, ci).expand(b, co, ci), x.reshape(b, ci, h * w))
     if conv.bias is not None:
         y = y + conv.bias.view(1, co, 1)

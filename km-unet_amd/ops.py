@@ -455,6 +455,56 @@ def qkv_gate(qkv):
     return QkvGateFn.apply(qkv)
 
 
+# ------------------------------------------------------------------------------------------ pointwise conv
+def pwconv_supported(ci, co, hw):
+    return ci % 16 == 0 and co % 16 == 0 and 0 < ci <= 256 and 0 < co <= 256 and hw % 64 == 0
+
+
+class PwConvFn(torch.autograd.Function):
+    """y = conv1x1(act(x), weight) + bias with act = identity | exact GELU (KM_UNetV3_SH.py:120-124,174,221;
+    vim_utils_init.py:62-89); bias, GELU, GELU' and the bias gradient are folded into the three kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act_in):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        co, ci = weight.shape[:2]
+        w = _f32c(weight, "weight").view(co, ci)
+        B, _, H, W = x.shape
+        y = torch.empty(B, co, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("pwconv_fwd", (B, ci, co, H * W)), lib.kmu_pwconv_fwd, _ptr(x), _ptr(w),
+                         _ptr(None if bias is None else _f32c(bias, "bias")), _ptr(y), B, ci, co, H * W, int(act_in), _stream()),
+                   "kmu_pwconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (bias is not None, int(act_in), tuple(weight.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        has_bias, act_in, wshape = ctx.cfg
+        g = _f32c(g, "grad")
+        B, ci, H, W = x.shape
+        co, P = w.shape[0], H * W
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(_call(("pwconv_bwd_input", (B, ci, co, P)), lib.kmu_pwconv_bwd_input, _ptr(g), _ptr(w),
+                             _ptr(x) if act_in else None, _ptr(dx), B, ci, co, P, act_in, _stream()), "kmu_pwconv_bwd_input")
+        nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        dw = torch.empty(co, ci, device=x.device, dtype=torch.float32)
+        db = torch.empty(co, device=x.device, dtype=torch.float32) if has_bias else None
+        _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight, _ptr(x), _ptr(g), _ptr(dw), _ptr(db),
+                         _ptr(ws), nbytes, B, ci, co, P, act_in, _stream()), "kmu_pwconv_bwd_weight")
+        return dx, dw.view(wshape), db, None
+
+
+def pwconv(x, weight, bias=None, act_in=False):
+    return PwConvFn.apply(x, weight, bias, act_in)
+
+
 # ------------------------------------------------------------------------------------------ GroupNorm
 class GroupNormFn(torch.autograd.Function):
     """nn.GroupNorm(G, C) forward/backward (KM_UNetV3_SH.py:57,271-273,294,448)."""

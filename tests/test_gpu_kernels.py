@@ -318,6 +318,41 @@ def test_qkv_gate_vs_torch_cpu():
     _report("qkv_gate", y=rel_err(y, yo), dqkv=rel_err(d.grad, qkv.grad))
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,bias,gelu", [
+    (2, 16, 48, 16, 16, True, False),     # qkv projection, C = 16
+    (2, 64, 256, 8, 8, False, False),     # EfficientViM FFN fc1 at the 64-channel level (bias-free)
+    (2, 256, 64, 8, 8, True, True),       # EnhancedViMBlock.ffn[2] with the GELU folded into its load
+    (1, 192, 64, 8, 16, False, False),    # 12 -> 4 tiles: contraction over 3 x 64 channels
+    (3, 32, 32, 16, 8, True, False),      # 'channel' projection; P = 128 leaves waves idle in the 256-pixel block
+    (2, 48, 16, 8, 8, True, True),        # 3-tile contraction, 1-tile output
+    (8, 16, 64, 128, 128, True, False),   # bench shape: every wave walks several chunks in bwd_weight
+])
+def test_pwconv_vs_torch_cpu(B, Ci, Co, H, W, bias, gelu):
+    """Pointwise conv kernels (csrc/pwconv.hip) against torch's fp64 CPU conv2d (+ exact GELU)."""
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(Ci * 7 + Co)
+    x = torch.randn(B, Ci, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 1, 1, generator=gen, dtype=torch.float64) / Ci ** 0.5).requires_grad_(True)
+    bv = torch.randn(Co, generator=gen, dtype=torch.float64).requires_grad_(True) if bias else None
+    gy = torch.randn(B, Co, H, W, generator=gen, dtype=torch.float64)
+    yo = F.conv2d(F.gelu(x) if gelu else x, w, bv)
+    yo.backward(gy)
+    xd, wd = x.detach().float().to(DEV).requires_grad_(True), w.detach().float().to(DEV).requires_grad_(True)
+    bd = bv.detach().float().to(DEV).requires_grad_(True) if bias else None
+    assert ops.pwconv_supported(Ci, Co, H * W)
+    y = ops.pwconv(xd, wd, bd, gelu)
+    y.backward(gy.float().to(DEV))
+    errs = dict(y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad), dw=rel_err(wd.grad, w.grad))
+    if bias:
+        errs["db"] = rel_err(bd.grad, bv.grad)
+    _report("pwconv %s" % ((B, Ci, Co, H, W, bias, gelu),), **errs)
+    # determinism of the two-stage weight-gradient reduction
+    xd2, wd2 = xd.detach().clone().requires_grad_(True), wd.detach().clone().requires_grad_(True)
+    ops.pwconv(xd2, wd2, None if bd is None else bd.detach(), gelu).backward(gy.float().to(DEV))
+    assert torch.equal(wd2.grad, wd.grad) and torch.equal(xd2.grad, xd.grad)
+
+
 # ------------------------------------------------------------------------------------------ blocks
 @pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
 def test_evim_block_golden(name, train):
