@@ -19,8 +19,9 @@
 //   bwd_weight      : M = out channels, N = in channels, K = pixels.  Lane (r = l%16, q) loads 2 float4 = pixels
 //     p0 + 8q .. 8q+7 of row r of each gy / x tile; K-step s pairs component s of both (pixel p0 + 8q + s).
 // Weights are staged once per workgroup in LDS as wl[k][n] (row stride = 16 mod 32 words: conflict-free
-// ds_read_b32 B fragments).  bwd_weight needs no LDS: every wave dumps its accumulators as a slab and
-// pw_wgrad_reduce_kernel adds the slabs in a fixed order (deterministic, no atomics).
+// ds_read_b32 B fragments).  bwd_weight streams straight from HBM into MFMA operands; LDS only adds the 4 waves'
+// accumulators, each workgroup dumps one slab and pw_wgrad_reduce_kernel adds the slabs in a fixed order
+// (deterministic, no atomics).
 #include "common.h"
 
 using kmu::floatx4;
@@ -122,11 +123,33 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------- bwd_weight
 // grid.x = G pixel groups, grid.y = (Co/16MT) * (Ci/16NT) slice pairs; 4 waves, each walks 32-pixel chunks
-// (chunk id = (g*4 + wave) + j * 4G) and dumps its accumulators to slab[sp][g*4+wave][mt][nt][lane] (float4).
+// (chunk id = (g*4 + wave) + j * 4G, next chunk prefetched into registers), the 4 waves' accumulators are added
+// through LDS (fixed order) and the workgroup dumps slab[sp][g][mt][nt][lane] (float4 per lane).
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_load(floatx4 (&a)[MT][2], floatx4 (&bx)[NT][2], const float* __restrict__ x,
+                                           const float* __restrict__ gy, int ch, int cpp, int Ci, int Co, int P, int co0, int ci0,
+                                           int r, int q) {
+    const int b = ch / cpp, p0 = (ch - b * cpp) * 32 + 8 * q;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float* g = gy + ((size_t)b * Co + co0 + 16 * mt + r) * P + p0;
+        a[mt][0] = *reinterpret_cast<const floatx4*>(g);
+        a[mt][1] = *reinterpret_cast<const floatx4*>(g + 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float* xp = x + ((size_t)b * Ci + ci0 + 16 * nt + r) * P + p0;
+        bx[nt][0] = *reinterpret_cast<const floatx4*>(xp);
+        bx[nt][1] = *reinterpret_cast<const floatx4*>(xp + 4);
+    }
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                        float* __restrict__ slab, float* __restrict__ bslab, int Ci, int Co,
                                                        int P, int nchunks, int act_in) {
+    __shared__ floatx4 red[3][MT * NT][64];
+    __shared__ float bred[3][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int nsl_i = Ci / (16 * NT);
@@ -142,21 +165,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
+    floatx4 a[MT][2], bx[NT][2], an[MT][2], bn[NT][2];
+    if (gw < nchunks) wgrad_load<MT, NT>(a, bx, x, gy, gw, cpp, Ci, Co, P, co0, ci0, r, q);
     for (int ch = gw; ch < nchunks; ch += nw) {
-        const int b = ch / cpp, p0 = (ch - b * cpp) * 32 + 8 * q;
-        floatx4 a[MT][2], bx[NT][2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float* g = gy + ((size_t)b * Co + co0 + 16 * mt + r) * P + p0;
-            a[mt][0] = *reinterpret_cast<const floatx4*>(g);
-            a[mt][1] = *reinterpret_cast<const floatx4*>(g + 4);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float* xp = x + ((size_t)b * Ci + ci0 + 16 * nt + r) * P + p0;
-            bx[nt][0] = *reinterpret_cast<const floatx4*>(xp);
-            bx[nt][1] = *reinterpret_cast<const floatx4*>(xp + 4);
-        }
+        const bool more = ch + nw < nchunks;
+        if (more) wgrad_load<MT, NT>(an, bn, x, gy, ch + nw, cpp, Ci, Co, P, co0, ci0, r, q);
         if (act_in) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -174,45 +187,84 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s >> 2][s & 3], bx[nt][s >> 2][s & 3], acc[mt][nt], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt][0] = an[mt][0], a[mt][1] = an[mt][1];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bx[nt][0] = bn[nt][0], bx[nt][1] = bn[nt][1];
+        }
     }
-    float* out = slab + (((size_t)sp * nw + gw) * MT * NT) * 256 + lane * 4;
+    const bool want_bias = bslab && sp % nsl_i == 0;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<floatx4*>(out + (mt * NT + nt) * 256) = acc[mt][nt];
-    if (bslab && sp % nsl_i == 0) {
+    for (int mt = 0; mt < MT; ++mt) {
+        bs[mt] += __shfl_xor(bs[mt], 16);
+        bs[mt] += __shfl_xor(bs[mt], 32);
+    }
+    if (wave > 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            float v = bs[mt];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (q == 0) bslab[((size_t)(sp / nsl_i) * nw + gw) * MT * 16 + mt * 16 + r] = v;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) red[wave - 1][mt * NT + nt][lane] = acc[mt][nt];
+            if (want_bias && q == 0) bred[wave - 1][mt][r] = bs[mt];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = slab + (((size_t)sp * gridDim.x + blockIdx.x) * MT * NT) * 256 + lane * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                floatx4 v = acc[mt][nt];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[w][mt * NT + nt][lane];
+                *reinterpret_cast<floatx4*>(out + (mt * NT + nt) * 256) = v;
+            }
+            if (want_bias && q == 0)
+                bslab[((size_t)(sp / nsl_i) * gridDim.x + blockIdx.x) * MT * 16 + mt * 16 + r] =
+                    bs[mt] + bred[0][mt][r] + bred[1][mt][r] + bred[2][mt][r];
         }
     }
 }
 
-// one thread per accumulator float4: (sp, mt, nt, lane) -> rows co = co0 + 16mt + 4q + i, column ci = ci0 + 16nt + r
+// 256 threads = 16 accumulator float4s x 16 partitions of the G slabs; partition sums meet in LDS in a fixed order.
+// float4 (sp, mt, nt, lane) -> rows co = co0 + 16mt + 4q + i, column ci = ci0 + 16nt + r.  Bias: blocks past the
+// weight range, 16 channels x 16 partitions each.
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
                                                               float* __restrict__ dw, float* __restrict__ dbias, int Ci, int Co,
-                                                              int MT, int NT, int nw) {
-    const int per_sp = MT * NT * 64, nsl_i = Ci / (16 * NT), nsp = (Co / (16 * MT)) * nsl_i;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < nsp * per_sp) {
+                                                              int MT, int NT, int G, int wblocks) {
+    __shared__ floatx4 part[16][16];
+    const int o = threadIdx.x & 15, pt = threadIdx.x >> 4;
+    const int per_sp = MT * NT * 64, nsl_i = Ci / (16 * NT);
+    if ((int)blockIdx.x < wblocks) {
+        const int t = blockIdx.x * 16 + o;                 // float4 id; per_sp % 16 == 0 so a block stays inside one tile
         const int sp = t / per_sp, e = t - sp * per_sp, tile = e >> 6, lane = e & 63;
-        const int mt = tile / NT, nt = tile - mt * NT, r = lane & 15, q = lane >> 4;
-        const float* src = slab + ((size_t)sp * nw * MT * NT + tile) * 256 + lane * 4;
+        const float* src = slab + ((size_t)sp * G * MT * NT + tile) * 256 + lane * 4;
         floatx4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int g = 0; g < nw; ++g) s += *reinterpret_cast<const floatx4*>(src + (size_t)g * MT * NT * 256);
-        const int co = (sp / nsl_i) * 16 * MT + 16 * mt + 4 * q, ci = (sp % nsl_i) * 16 * NT + 16 * nt + r;
+        for (int g = pt; g < G; g += 16) s += *reinterpret_cast<const floatx4*>(src + (size_t)g * MT * NT * 256);
+        part[pt][o] = s;
+        __syncthreads();
+        if (pt == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dw[(size_t)(co + i) * Ci + ci] = s[i];
-    }
-    if (dbias && t < Co) {
+            for (int k = 1; k < 16; ++k) s += part[k][o];
+            const int mt = tile / NT, nt = tile - mt * NT, r = lane & 15, q = lane >> 4;
+            const int co = (sp / nsl_i) * 16 * MT + 16 * mt + 4 * q, ci = (sp % nsl_i) * 16 * NT + 16 * nt + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw[(size_t)(co + i) * Ci + ci] = s[i];
+        }
+    } else {
+        const int t = (blockIdx.x - wblocks) * 16 + o;     // output channel (Co % 16 == 0)
         const int so = t / (16 * MT), rem = t - so * 16 * MT;
-        const float* src = bslab + (size_t)so * nw * MT * 16 + rem;
+        const float* src = bslab + (size_t)so * G * MT * 16 + rem;
         float s = 0.f;
-        for (int g = 0; g < nw; ++g) s += src[(size_t)g * MT * 16];
-        dbias[t] = s;
+        for (int g = pt; g < G; g += 16) s += src[(size_t)g * MT * 16];
+        part[pt][o][0] = s;
+        __syncthreads();
+        if (pt == 0) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) s += part[k][o][0];
+            dbias[t] = s;
+        }
     }
 }
 
@@ -229,13 +281,13 @@ inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
     pl.NT = pick_tiles(Ci / 16);
     pl.nsp = (Co / (16 * pl.MT)) * (Ci / (16 * pl.NT));
     pl.nchunks = B * (P / 32);
-    int G = pl.nchunks / 16;                       // >= 4 chunks per wave
-    G = G < 1 ? 1 : (G > 256 ? 256 : G);
-    while (G > 32 && (size_t)G * 4 * pl.MT * pl.NT * 1024 * pl.nsp > ((size_t)8 << 20)) G /= 2;   // keep the slabs <= 8 MB
+    int G = pl.nchunks / 8;                        // >= 2 chunks per wave
+    G = G < 1 ? 1 : (G > 512 ? 512 : G);
+    while (G > 32 && (size_t)G * pl.MT * pl.NT * 1024 * pl.nsp > ((size_t)4 << 20)) G /= 2;   // keep the slabs <= 4 MB
     pl.G = G;
     pl.nw = 4 * G;
-    pl.slab_floats = (size_t)pl.nsp * pl.nw * pl.MT * pl.NT * 256;
-    pl.bslab_floats = (size_t)(Co / (16 * pl.MT)) * pl.nw * pl.MT * 16;
+    pl.slab_floats = (size_t)pl.nsp * G * pl.MT * pl.NT * 256;
+    pl.bslab_floats = (size_t)(Co / (16 * pl.MT)) * G * pl.MT * 16;
     return pl;
 }
 
@@ -324,9 +376,8 @@ extern "C" int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw,
     }
     int rc = kmu::launch_status("pwconv_bwd_weight");
     if (rc) return rc;
-    const int threads = pl.nsp * pl.MT * pl.NT * 64;
-    const int need = threads > Co ? threads : Co;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((need + 255) / 256), dim3(256), 0, st, slab, bslab, dw, dbias, Ci, Co, pl.MT, pl.NT,
-                       pl.nw);
+    const int wblocks = pl.nsp * pl.MT * pl.NT * 64 / 16, bblocks = dbias ? Co / 16 : 0;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, slab, bslab, dw, dbias, Ci, Co, pl.MT, pl.NT,
+                       pl.G, wblocks);
     return kmu::launch_status("pwconv_bwd_weight(reduce)");
 }
