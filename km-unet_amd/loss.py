@@ -18,11 +18,15 @@ class HybridLoss(nn.Module):
         dist = torch.arange((1 - kernel_size) / 2, (1 + kernel_size) / 2, 1)
         g = torch.exp(-((dist / sigma) ** 2) / 2)
         self.register_buffer("gauss", g / g.sum(), persistent=False)
+        self._taps = {}
 
     def _filter(self, x):
         c = x.shape[1]
-        gh = self.gauss.view(1, 1, self.k, 1).expand(c, 1, self.k, 1)
-        gw = self.gauss.view(1, 1, 1, self.k).expand(c, 1, 1, self.k)
+        key = (c, x.device)
+        if key not in self._taps:      # packed per-channel copies (a stride-0 expand() sends MIOpen to its naive kernels)
+            g = self.gauss.to(x.device)
+            self._taps[key] = (g.view(1, 1, self.k, 1).repeat(c, 1, 1, 1), g.view(1, 1, 1, self.k).repeat(c, 1, 1, 1))
+        gh, gw = self._taps[key]
         return F.conv2d(F.conv2d(x, gh, groups=c), gw, groups=c)
 
     def ssim(self, p, t):

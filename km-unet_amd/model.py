@@ -123,7 +123,11 @@ class TripleNorm(nn.Module):
         self.norm_c = nn.LayerNorm(dim)
 
     def forward(self, x):
-        c = self.norm_c(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        if "layer_norm" in _TORCH_GLUE:
+            c = self.norm_c(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        else:       # LayerNorm over C at every pixel == LayerNorm1D over [B,C,HW]: the K2 front-end kernel, no permutes
+            n = self.norm_c
+            c = ops.layernorm1d(x.flatten(2), n.weight.view(1, -1, 1), n.bias.view(1, -1, 1), n.eps).view_as(x)
         return (group_norm(x, self.norm_h) + group_norm(x, self.norm_w) + c) / 3
 
 

@@ -13,7 +13,8 @@ from .loss import HybridLoss
 
 def split_frames(data):
     data = data.squeeze(2)
-    return data[:, :5].float(), data[:, 5:].float()
+    # packed copies: MIOpen serves strided (non-packed) conv inputs with its naive kernels
+    return data[:, :5].float().contiguous(), data[:, 5:].float().contiguous()
 
 
 class TrainStep:
@@ -31,10 +32,9 @@ class TrainStep:
 
     def forward_backward(self, data):
         inp, tgt = split_frames(data)
-        self.dp.zero_grad()
         out = self.model(inp)
         loss = self.criterion(out, tgt)
-        loss.backward()
+        self.dp.backward(loss)
         return loss
 
     def __call__(self, data):
