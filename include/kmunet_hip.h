@@ -220,6 +220,14 @@ int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbi
                           int Co, int P, int act_in, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Second stage of the two-stage (deterministic) parameter-gradient reductions: column sums of up to 8 partial
+ * arrays src[k] = [rows[k]][cols[k]] -> dst[k] = [cols[k]] in one launch.  srcs/dsts/rows/cols are HOST arrays of
+ * length n holding device pointers / sizes.  (No reference counterpart: autograd's SumBackward does this.)
+ * ------------------------------------------------------------------------------------ */
+int kmu_colsum_multi(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols,
+                     kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * GroupNorm(G, C) over [B,C,HW]: StableHybridKANConv.pre_norm (KM_UNetV3_SH.py:57,73), TripleNorm.norm_h/w
  * (:271-273), MultiScaleFusion (:294), KM_UNetV3.output_norm (:448,516).  stats [B,G,2] = (mean, rstd);
  * ws: [B*C*S*2] floats, S = kmu_group_norm_splits(HW); d_gamma/d_beta leave as [B,C] partials.

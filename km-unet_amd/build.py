@@ -27,6 +27,7 @@ SOURCES = [
     ("qkv_gate.hip", []),
     ("group_norm.hip", []),
     ("pwconv.hip", []),
+    ("colsum.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -13,9 +13,10 @@
 // MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32).  Both the 16 "M" rows and the 4 "K" slots of an MFMA are
 // free permutations as long as A, B and D agree, which lets every lane issue 16-byte loads straight from NCHW:
 //   fwd / bwd_input : M = pixels, N = out channels, K = in channels.  Lane (m = l%16, q = l/16) loads ONE float4
-//     x[ch(c,s,q)][p0 + 4m .. 4m+3], ch = 16c + 4q + s: its 4 components are the A operands of 4 M-tiles t
-//     (pixel(m,t) = p0 + 4m + t).  A D tile then holds, per lane, pixels p0 + 16q + 4i + t -> with the 4 tiles
-//     side by side each lane owns 16 consecutive pixels of one output channel: 4 float4 stores.
+//     x[ch(c,s,q)][p0 + 4 f(m) .. +3], ch = 16c + 4q + s, f(m) = m/4 + 4 (m%4): its 4 components are the A operands
+//     of 4 M-tiles t (pixel(m,t) = p0 + 4 f(m) + t).  D row 4q + i is then pixel p0 + 16i + 4q + t: for each i the 4
+//     tiles side by side give every lane one float4 and the 4 lanes q of an output channel 64 contiguous bytes per
+//     store instruction (f = identity would scatter 16-byte pieces at a 64-byte stride).
 //   bwd_weight      : M = out channels, N = in channels, K = pixels.  Lane (r = l%16, q) loads 2 float4 = pixels
 //     p0 + 8q .. 8q+7 of row r of each gy / x tile; K-step s pairs component s of both (pixel p0 + 8q + s).
 // Weights are staged once per workgroup in LDS as wl[k][n] (row stride = 16 mod 32 words: conflict-free
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     __syncthreads();
     if (p0 >= P) return;
 
-    const float* xb = x + (size_t)b * K * P + p0 + 4 * m;
+    const float* xb = x + (size_t)b * K * P + p0 + 4 * ((m >> 2) + 4 * (m & 3));
     floatx4 acc[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -102,21 +103,21 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
         for (int s = 0; s < 4; ++s) xv[s] = xn[s];
     }
 
-    // epilogue: lane owns channel n0 + 16nt + m, pixels p0 + 16q + 4i + t
+    // epilogue: lane owns channel n0 + 16nt + m, pixels p0 + 16i + 4q + t
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + 16 * nt + m;
         const float bv = bias ? bias[n] : 0.f;
-        const size_t off = ((size_t)b * N + n) * P + p0 + 16 * q;
+        const size_t off = ((size_t)b * N + n) * P + p0 + 4 * q;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             floatx4 o = {acc[nt][0][i] + bv, acc[nt][1][i] + bv, acc[nt][2][i] + bv, acc[nt][3][i] + bv};
             if (mul_pre) {
-                const floatx4 z = *reinterpret_cast<const floatx4*>(mul_pre + off + 4 * i);
+                const floatx4 z = *reinterpret_cast<const floatx4*>(mul_pre + off + 16 * i);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] *= gelu_grad_f(z[t]);
             }
-            *reinterpret_cast<floatx4*>(y + off + 4 * i) = o;
+            *reinterpret_cast<floatx4*>(y + off + 16 * i) = o;
         }
     }
 }

@@ -54,6 +54,24 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def colsum(*partials):
+    """Column sums of per-workgroup partial arrays [rows, ...] -> [...] for up to 8 arrays in ONE launch
+    (csrc/colsum.hip): the second stage of every deterministic two-stage parameter-gradient reduction."""
+    import ctypes
+    lib = _lib.load()
+    parts = [p for p in partials if p is not None]
+    outs = [torch.empty(p.shape[1:], device=p.device, dtype=torch.float32) for p in parts]
+    n = len(parts)
+    srcs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts])
+    dsts = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    rows = (ctypes.c_int * n)(*[p.shape[0] for p in parts])
+    cols = (ctypes.c_int * n)(*[max(1, o.numel()) for o in outs])
+    _lib.check(_call(("colsum_multi", tuple(int(p.numel()) for p in parts)), lib.kmu_colsum_multi, n, srcs, dsts, rows, cols,
+                     _stream()), "kmu_colsum_multi")
+    it = iter(outs)
+    return [None if p is None else next(it) for p in partials]
+
+
 # ------------------------------------------------------------------------------------------ K1
 _GRID_OK = set()
 
@@ -164,7 +182,8 @@ class LayerNorm1dFn(torch.autograd.Function):
         dbp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
         _lib.check(lib.kmu_layernorm1d_bwd(_ptr(x), _ptr(w), _ptr(stats), _ptr(dy), _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, L,
                                            _stream()), "kmu_layernorm1d_bwd")
-        return dx, dwp.sum(0).view(ctx.wshape), dbp.sum(0).view(ctx.wshape), None
+        dw, db = colsum(dwp, dbp)
+        return dx, dw.view(ctx.wshape), db.view(ctx.wshape), None
 
 
 def layernorm1d(x, weight, bias, eps=1e-5):
@@ -227,8 +246,9 @@ class HsmssdFn(torch.autograd.Function):
                              _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, st), "kmu_hsmssd_bwd_stage")
         # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd
         # returns ~1e-7 rounding noise here)
-        return (dx, p_bcdt.sum(0).view(3 * N, C, 1), p_dw.sum(0).view(3 * N, 1, 3, 3), p_hz.sum(0).view(2 * C, C, 1),
-                p_out.sum(0).view(C, C, 1), torch.zeros(ctx.A_shape, device=dev), p_D.sum().view(1))
+        d_bcdt, d_dw, d_hz, d_out, d_D = colsum(p_bcdt, p_dw, p_hz, p_out, p_D.view(G, 1))
+        return (dx, d_bcdt.view(3 * N, C, 1), d_dw.view(3 * N, 1, 3, 3), d_hz.view(2 * C, C, 1), d_out.view(C, C, 1),
+                torch.zeros(ctx.A_shape, device=dev), d_D.view(1))
 
 
 def hsmssd(x, w_bcdt, w_dw, w_hz, w_out, A, D):
@@ -355,8 +375,8 @@ class DwConv3x3Fn(torch.autograd.Function):
             dbp = torch.empty(P, C, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dy), _ptr(dwp),
                              _ptr(dbp), B, C, H, W, st), "kmu_dwconv3x3_bwd_weight")
-            dw = dwp.sum(0).view(C, 1, 3, 3)
-            db = dbp.sum(0) if ctx.has_bias else None
+            dw, db = colsum(dwp, dbp)
+            dw = dw.view(C, 1, 3, 3)
         return dx, dw, db
 
 
@@ -537,7 +557,8 @@ class GroupNormFn(torch.autograd.Function):
         ws = torch.empty(B * C * S * 2, device=x.device, dtype=torch.float32)
         _lib.check(_call(("group_norm_bwd", (B, C, G, HW)), lib.kmu_group_norm_bwd, _ptr(x), _ptr(g), _ptr(gamma), _ptr(stats),
                          _ptr(dx), _ptr(dgp), _ptr(dbp), _ptr(ws), B, C, G, HW, _stream()), "kmu_group_norm_bwd")
-        return dx, dgp.sum(0), dbp.sum(0), None, None
+        dg, db = colsum(dgp, dbp)
+        return dx, dg, db, None, None
 
 
 def group_norm(x, gn):

@@ -353,6 +353,25 @@ def test_pwconv_vs_torch_cpu(B, Ci, Co, H, W, bias, gelu):
     assert torch.equal(wd2.grad, wd.grad) and torch.equal(xd2.grad, xd.grad)
 
 
+def test_colsum_multi_vs_torch():
+    """csrc/colsum.hip: ragged row / column counts, 1..8 arrays per launch, deterministic."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(11)
+    shapes = [(1, 1), (7, 27), (1024, 100), (33, 3, 5), (8, 1), (129, 64), (2, 31), (500, 33)]
+    parts = [torch.randn(*s, generator=gen).to(DEV) for s in shapes]
+    for n in (1, 3, 8):
+        outs = ops.colsum(*parts[:n])
+        for p, o in zip(parts[:n], outs):
+            assert o.shape == p.shape[1:]
+            assert rel_err(o, p.double().sum(0)) < 1e-5
+        again = ops.colsum(*parts[:n])
+        assert all(torch.equal(a, b) for a, b in zip(outs, again))
+    mixed = ops.colsum(parts[0], None, parts[1])
+    assert mixed[1] is None and rel_err(mixed[2], parts[1].double().sum(0)) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.colsum(*(parts + parts[:1]))        # 9 arrays
+
+
 # ------------------------------------------------------------------------------------------ blocks
 @pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
 def test_evim_block_golden(name, train):
