@@ -220,6 +220,20 @@ int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbi
                           int Co, int P, int act_in, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Squeeze-excite gates on pooled vectors:  g = act2(W2 . act1(W1 . p + b1) + b2),  p [B,I], W1 [H,I], W2 [O,H].
+ * DirectionAttention.fc (KM_UNetV3_SH.py:231-236), EnhancedViMBlock.fusion_gate (:111-117, on the pooled means),
+ * ChannelAttention.fc (:320-325), LocalContrastAttention.fc (:342-347).  act1: 0 GELU (erf), 1 SiLU, 2 ReLU;
+ * act2: 0 sigmoid, 1 softmax over O.  fwd also returns z1 = W1 p + b1 [B,H] for the backward; bwd writes final
+ * (batch-summed) dw1 [H,I], db1 [H], dw2 [O,H], db2 [O] and dp [B,I] (b1/b2/db1/db2/dp may be NULL).
+ * One workgroup; B*(I+2H+O)*4 bytes must fit 144 KB of LDS.
+ * ------------------------------------------------------------------------------------ */
+int kmu_gate_mlp_fwd(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, float* z1, float* g,
+                     int B, int I, int H, int O, int act1, int act2, kmu_stream_t stream);
+int kmu_gate_mlp_bwd(const float* p, const float* w1, const float* w2, const float* z1, const float* g, const float* dg,
+                     float* dp, float* dw1, float* db1, float* dw2, float* db2, int B, int I, int H, int O, int act1, int act2,
+                     kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Second stage of the two-stage (deterministic) parameter-gradient reductions: column sums of up to 8 partial
  * arrays src[k] = [rows[k]][cols[k]] -> dst[k] = [cols[k]] in one launch.  srcs/dsts/rows/cols are HOST arrays of
  * length n holding device pointers / sizes.  (No reference counterpart: autograd's SumBackward does this.)

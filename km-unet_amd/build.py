@@ -28,6 +28,7 @@ SOURCES = [
     ("group_norm.hip", []),
     ("pwconv.hip", []),
     ("colsum.hip", []),
+    ("gate_mlp.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

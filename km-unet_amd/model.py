@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1, group_norm
+from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1, gate_mlp, group_norm
 
 
 import os as _os
@@ -83,7 +83,7 @@ class DirectionAttention(nn.Module):
 
     def forward(self, x):
         b, c = x.shape[:2]
-        gate = self.fc(x.mean(dim=(2, 3)))
+        gate = gate_mlp(x.mean(dim=(2, 3)), self.fc[0], self.fc[2], "gelu")
         qkv = conv1x1(x, self.qkv)
         if (qkv.shape[2] * qkv.shape[3]) % 4 == 0 and "qkv_gate" not in _TORCH_GLUE:
             attn = ops.qkv_gate(qkv)                       # sigmoid(q*k)*v, one HIP kernel
@@ -168,7 +168,9 @@ class EnhancedViMBlock(nn.Module):
 
     def forward(self, x):
         feats = self._branches(x)
-        g = self.fusion_gate(torch.cat(feats, dim=1))
+        # fusion_gate = pool . conv1x1 . GELU . conv1x1 . softmax: pooling commutes with the channel concat
+        pooled = torch.cat([f.mean(dim=(2, 3)) for f in feats], dim=1)
+        g = gate_mlp(pooled, self.fusion_gate[1], self.fusion_gate[3], "gelu", "softmax")[:, :, None, None]
         x = x + self.drop_path(g[:, 0:1] * feats[0] + g[:, 1:2] * feats[1] + g[:, 2:3] * feats[2])
         f = conv1x1(conv1x1(self.norm(x), self.ffn[0]), self.ffn[2], gelu_in=True)   # GELU folded into ffn[2]'s load
         return x + self.drop_path(f)
@@ -183,7 +185,7 @@ class ChannelAttention(nn.Module):
 
     def forward(self, x):
         b, c = x.shape[:2]
-        return x * self.fc(x.mean(dim=(2, 3))).view(b, c, 1, 1)
+        return x * gate_mlp(x.mean(dim=(2, 3)), self.fc[0], self.fc[2], "silu").view(b, c, 1, 1)
 
 
 class MultiScaleFusion(nn.Module):
@@ -211,7 +213,7 @@ class LocalContrastAttention(nn.Module):
 
     def forward(self, x):
         avg = x.mean(dim=(2, 3))
-        g = self.fc(avg.view(avg.shape[0], -1, self.reduction_ratio).mean(-1))[:, :, None, None]
+        g = gate_mlp(avg.view(avg.shape[0], -1, self.reduction_ratio).mean(-1), self.fc[0], self.fc[2], "relu")[:, :, None, None]
         return torch.lerp(x, torch.ones_like(x), g)          # x*(1-g) + g
 
 

@@ -38,6 +38,16 @@ def conv1x1(x, conv, gelu_in=False):
     return y.view(b, co, h, w)
 
 
+def gate_mlp(p, lin1, lin2, act1, act2="sigmoid"):
+    """act2(lin2(act1(lin1(p)))) for pooled [B, I] vectors; lin1/lin2 are nn.Linear or 1x1 nn.Conv2d modules
+    (csrc/gate_mlp.hip: one launch each way).  KMU_GLUE_TORCH=gate_mlp keeps the ATen sequence."""
+    if "gate_mlp" in _TORCH_GLUE:
+        f = {"gelu": F.gelu, "silu": F.silu, "relu": F.relu}[act1]
+        z = F.linear(f(F.linear(p, lin1.weight.flatten(1), lin1.bias)), lin2.weight.flatten(1), lin2.bias)
+        return torch.sigmoid(z) if act2 == "sigmoid" else torch.softmax(z, dim=1)
+    return ops.gate_mlp(p, lin1.weight, lin1.bias, lin2.weight, lin2.bias, act1, act2)
+
+
 def group_norm(x, gn):
     """nn.GroupNorm through the HIP kernels (csrc/group_norm.hip); KMU_GLUE_TORCH=group_norm keeps ATen's."""
     if "group_norm" in _TORCH_GLUE:

@@ -525,6 +525,53 @@ def pwconv(x, weight, bias=None, act_in=False):
     return PwConvFn.apply(x, weight, bias, act_in)
 
 
+# ------------------------------------------------------------------------------------------ squeeze-excite gates
+_ACT1 = {"gelu": 0, "silu": 1, "relu": 2}
+_ACT2 = {"sigmoid": 0, "softmax": 1}
+
+
+class GateMlpFn(torch.autograd.Function):
+    """g = act2(W2 act1(W1 p + b1) + b2) on pooled [B, I] vectors (KM_UNetV3_SH.py:111-117,231-236,320-325,342-347):
+    one launch forward, one backward (weight gradients summed over the batch in-kernel)."""
+
+    @staticmethod
+    def forward(ctx, p, w1, b1, w2, b2, act1, act2):
+        lib = _lib.load()
+        p = _f32c(p, "pooled input")
+        B, I = p.shape
+        H, O = w1.shape[0], w2.shape[0]
+        w1c, w2c = _f32c(w1, "w1").view(H, I), _f32c(w2, "w2").view(O, H)
+        z1 = torch.empty(B, H, device=p.device, dtype=torch.float32)
+        g = torch.empty(B, O, device=p.device, dtype=torch.float32)
+        _lib.check(_call(("gate_mlp_fwd", (B, I, H, O)), lib.kmu_gate_mlp_fwd, _ptr(p), _ptr(w1c), _ptr(None if b1 is None else _f32c(b1, "b1")),
+                         _ptr(w2c), _ptr(None if b2 is None else _f32c(b2, "b2")), _ptr(z1), _ptr(g), B, I, H, O, _ACT1[act1], _ACT2[act2],
+                         _stream()), "kmu_gate_mlp_fwd")
+        ctx.save_for_backward(p, w1c, w2c, z1, g)
+        ctx.cfg = (_ACT1[act1], _ACT2[act2], b1 is not None, b2 is not None, tuple(w1.shape), tuple(w2.shape))
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        lib = _lib.load()
+        p, w1, w2, z1, g = ctx.saved_tensors
+        a1, a2, hb1, hb2, s1, s2 = ctx.cfg
+        dg = _f32c(dg, "grad")
+        B, I = p.shape
+        H, O = w1.shape[0], w2.shape[0]
+        dev = p.device
+        dp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        dw1, dw2 = torch.empty(H, I, device=dev), torch.empty(O, H, device=dev)
+        db1 = torch.empty(H, device=dev) if hb1 else None
+        db2 = torch.empty(O, device=dev) if hb2 else None
+        _lib.check(_call(("gate_mlp_bwd", (B, I, H, O)), lib.kmu_gate_mlp_bwd, _ptr(p), _ptr(w1), _ptr(w2), _ptr(z1), _ptr(g), _ptr(dg),
+                         _ptr(dp), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), B, I, H, O, a1, a2, _stream()), "kmu_gate_mlp_bwd")
+        return dp, dw1.view(s1), db1, dw2.view(s2), db2, None, None
+
+
+def gate_mlp(p, w1, b1, w2, b2, act1="gelu", act2="sigmoid"):
+    return GateMlpFn.apply(p, w1, b1, w2, b2, act1, act2)
+
+
 # ------------------------------------------------------------------------------------------ GroupNorm
 class GroupNormFn(torch.autograd.Function):
     """nn.GroupNorm(G, C) forward/backward (KM_UNetV3_SH.py:57,271-273,294,448)."""

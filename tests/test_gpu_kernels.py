@@ -353,6 +353,35 @@ def test_pwconv_vs_torch_cpu(B, Ci, Co, H, W, bias, gelu):
     assert torch.equal(wd2.grad, wd.grad) and torch.equal(xd2.grad, xd.grad)
 
 
+@pytest.mark.parametrize("B,I,H,O,act1,act2,bias", [
+    (8, 16, 4, 16, "gelu", "sigmoid", True),      # DirectionAttention.fc, C = 16
+    (8, 192, 16, 3, "gelu", "softmax", True),     # EnhancedViMBlock.fusion_gate, C = 64
+    (8, 32, 8, 32, "silu", "sigmoid", True),      # ChannelAttention (reduction 4)
+    (8, 16, 64, 64, "relu", "sigmoid", True),     # LocalContrastAttention, C = 64
+    (3, 5, 7, 2, "gelu", "softmax", False),       # ragged, bias-free
+    (64, 192, 64, 64, "silu", "sigmoid", True),   # largest batch that fits the LDS budget comfortably
+])
+def test_gate_mlp_vs_torch_cpu(B, I, H, O, act1, act2, bias):
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(B * 131 + I)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
+    p, w1, w2 = mk(B, I), mk(H, I), mk(O, H)
+    b1, b2 = (mk(H), mk(O)) if bias else (None, None)
+    dg = torch.randn(B, O, generator=gen, dtype=torch.float64)
+    z = F.linear({"gelu": F.gelu, "silu": F.silu, "relu": F.relu}[act1](F.linear(p, w1, b1)), w2, b2)
+    go = torch.sigmoid(z) if act2 == "sigmoid" else torch.softmax(z, dim=1)
+    go.backward(dg)
+    dev = lambda t: None if t is None else t.detach().float().to(DEV).requires_grad_(True)
+    pd, w1d, b1d, w2d, b2d = dev(p), dev(w1), dev(b1), dev(w2), dev(b2)
+    g = ops.gate_mlp(pd, w1d, b1d, w2d, b2d, act1, act2)
+    g.backward(dg.float().to(DEV))
+    errs = dict(g=rel_err(g, go), dp=rel_err(pd.grad, p.grad), dw1=rel_err(w1d.grad, w1.grad), dw2=rel_err(w2d.grad, w2.grad))
+    if bias:
+        errs.update(db1=rel_err(b1d.grad, b1.grad), db2=rel_err(b2d.grad, b2.grad))
+    _report("gate_mlp %s" % ((B, I, H, O, act1, act2),), **errs)
+
+
 def test_colsum_multi_vs_torch():
     """csrc/colsum.hip: ragged row / column counts, 1..8 arrays per launch, deterministic."""
     ops = _ops()
