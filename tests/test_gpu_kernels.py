@@ -365,8 +365,9 @@ def test_gate_mlp_vs_torch_cpu(B, I, H, O, act1, act2, bias):
     import torch.nn.functional as F
     ops = _ops()
     gen = torch.Generator().manual_seed(B * 131 + I)
-    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
-    p, w1, w2 = mk(B, I), mk(H, I), mk(O, H)
+    mk = lambda *s: (torch.randn(*s, generator=gen, dtype=torch.float64) / (s[-1] ** 0.5 if len(s) > 1 else 1.0)).requires_grad_(True)
+    p, w1, w2 = mk(B, I), mk(H, I), mk(O, H)       # weights ~ 1/sqrt(fan_in): logits O(1), softmax not saturated
+    p = (p.detach() * I ** 0.5).requires_grad_(True)
     b1, b2 = (mk(H), mk(O)) if bias else (None, None)
     dg = torch.randn(B, O, generator=gen, dtype=torch.float64)
     z = F.linear({"gelu": F.gelu, "silu": F.silu, "relu": F.relu}[act1](F.linear(p, w1, b1)), w2, b2)
