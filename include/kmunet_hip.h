@@ -220,6 +220,15 @@ int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbi
                           int Co, int P, int act_in, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * IntelligentWaveletPoolingModule up to its fusion conv (WPL/iwp.py:124-130; Haar DWT_2D iwp.py:47-113):
+ * x [B,C,H,W] (H, W even) -> out [B,C+1,H/2,W/2] = cat[LL, mean over the 3C channels of cat[LH,HL,HH]].  The
+ * Softmax2d attention over one channel (iwp.py:127) is identically 1, its conv receives an exactly-zero gradient.
+ * bwd: gout [B,C+1,H/2,W/2] -> dx [B,C,H,W], written in full.
+ * ------------------------------------------------------------------------------------ */
+int kmu_iwp_front_fwd(const float* x, float* out, int B, int C, int H, int W, kmu_stream_t stream);
+int kmu_iwp_front_bwd(const float* gout, float* dx, int B, int C, int H, int W, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Squeeze-excite gates on pooled vectors:  g = act2(W2 . act1(W1 . p + b1) + b2),  p [B,I], W1 [H,I], W2 [O,H].
  * DirectionAttention.fc (KM_UNetV3_SH.py:231-236), EnhancedViMBlock.fusion_gate (:111-117, on the pooled means),
  * ChannelAttention.fc (:320-325), LocalContrastAttention.fc (:342-347).  act1: 0 GELU (erf), 1 SiLU, 2 ReLU;

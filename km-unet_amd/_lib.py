@@ -49,6 +49,8 @@ SIGNATURES = {
     "kmu_pwconv_bwd_input": (_I, [_P] * 4 + [_I] * 5 + [_P]),
     "kmu_pwconv_bwd_weight_ws_bytes": (_Z, [_I] * 4),
     "kmu_pwconv_bwd_weight": (_I, [_P] * 5 + [_Z] + [_I] * 5 + [_P]),
+    "kmu_iwp_front_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
+    "kmu_iwp_front_bwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_gate_mlp_fwd": (_I, [_P] * 7 + [_I] * 6 + [_P]),
     "kmu_gate_mlp_bwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "kmu_colsum_multi": (_I, [_I, _P, _P, _P, _P, _P]),

@@ -29,6 +29,7 @@ SOURCES = [
     ("pwconv.hip", []),
     ("colsum.hip", []),
     ("gate_mlp.hip", []),
+    ("iwp.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

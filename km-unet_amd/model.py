@@ -128,7 +128,11 @@ class TripleNorm(nn.Module):
         else:       # LayerNorm over C at every pixel == LayerNorm1D over [B,C,HW]: the K2 front-end kernel, no permutes
             n = self.norm_c
             c = ops.layernorm1d(x.flatten(2), n.weight.view(1, -1, 1), n.bias.view(1, -1, 1), n.eps).view_as(x)
-        return (group_norm(x, self.norm_h) + group_norm(x, self.norm_w) + c) / 3
+        if "group_norm" in _TORCH_GLUE:
+            return (group_norm(x, self.norm_h) + group_norm(x, self.norm_w) + c) / 3
+        # norm_h(x) + norm_w(x) share their statistics (same input, one group): xhat (g_h + g_w) + (b_h + b_w)
+        nh, nw = self.norm_h, self.norm_w
+        return (ops.GroupNormFn.apply(x, nh.weight + nw.weight, nh.bias + nw.bias, 1, nh.eps) + c) / 3
 
 
 class EnhancedViMBlock(nn.Module):

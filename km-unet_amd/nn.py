@@ -356,6 +356,9 @@ class IntelligentWaveletPoolingModule(nn.Module):
         self.fusion_conv = nn.Conv2d(in_channels + 1, in_channels, 1)
 
     def forward(self, x):
+        if "iwp" not in _TORCH_GLUE and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            # DWT + (identically-1) attention + channel mean + concat: one HIP stencil (csrc/iwp.hip)
+            return conv1x1(ops.iwp_front(x, self.high_freq_conv.weight, self.high_freq_conv.bias), self.fusion_conv)
         ll, lh, hl, hh = self.dwt(x)
         high = torch.cat([lh, hl, hh], dim=1)
         high = high * self.softmax(conv1x1(high, self.high_freq_conv))

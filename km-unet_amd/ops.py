@@ -525,6 +525,50 @@ def pwconv(x, weight, bias=None, act_in=False):
     return PwConvFn.apply(x, weight, bias, act_in)
 
 
+# ------------------------------------------------------------------------------------------ wavelet pooling front end
+_ZEROS = {}
+
+
+def _const_zeros(like):
+    """A shared, never-written all-zero tensor (gradients that are exactly zero by construction): no fill launch."""
+    key = (tuple(like.shape), like.device)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(like.shape, device=like.device, dtype=torch.float32)
+    return _ZEROS[key]
+
+
+class IwpFrontFn(torch.autograd.Function):
+    """cat[LL, mean(cat[LH, HL, HH] * Softmax2d(conv1x1(.)))] of WPL/iwp.py:124-130.  hf_weight / hf_bias are the
+    parameters of high_freq_conv: a softmax over its single output channel is identically 1, so they do not enter
+    the value and their gradient is exactly zero (returned as such so that they stay "live" for AdamW's decay)."""
+
+    @staticmethod
+    def forward(ctx, x, hf_weight, hf_bias):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, C, H, W = x.shape
+        out = torch.empty(B, C + 1, H // 2, W // 2, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("iwp_front_fwd", (B, C, H, W)), lib.kmu_iwp_front_fwd, _ptr(x), _ptr(out), B, C, H, W, _stream()),
+                   "kmu_iwp_front_fwd")
+        ctx.dims = (B, C, H, W)
+        ctx.zeros = (_const_zeros(hf_weight), None if hf_bias is None else _const_zeros(hf_bias))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, C, H, W = ctx.dims
+        g = _f32c(g, "grad")
+        dx = torch.empty(B, C, H, W, device=g.device, dtype=torch.float32)
+        _lib.check(_call(("iwp_front_bwd", (B, C, H, W)), lib.kmu_iwp_front_bwd, _ptr(g), _ptr(dx), B, C, H, W, _stream()),
+                   "kmu_iwp_front_bwd")
+        return dx, ctx.zeros[0], ctx.zeros[1]
+
+
+def iwp_front(x, hf_weight, hf_bias):
+    return IwpFrontFn.apply(x, hf_weight, hf_bias)
+
+
 # ------------------------------------------------------------------------------------------ squeeze-excite gates
 _ACT1 = {"gelu": 0, "silu": 1, "relu": 2}
 _ACT2 = {"sigmoid": 0, "softmax": 1}

@@ -383,6 +383,27 @@ def test_gate_mlp_vs_torch_cpu(B, I, H, O, act1, act2, bias):
     _report("gate_mlp %s" % ((B, I, H, O, act1, act2),), **errs)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(3, 5, 6, 10), (2, 16, 2, 2), (1, 64, 32, 32)])
+def test_iwp_front_vs_slicing(B, C, H, W):
+    """csrc/iwp.hip against the strided-slice restatement of WPL/iwp.py:124-130 (km-unet_amd/nn.py::_HaarDWT, itself
+    pinned by tests/golden/iwp_c16.npz through test_iwp_golden) in fp64 on the CPU."""
+    import km_unet_amd
+    from km_unet_amd.nn import _HaarDWT
+    ops = _ops()
+    gen = torch.Generator().manual_seed(B + C + H)
+    x = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
+    g = torch.randn(B, C + 1, H // 2, W // 2, generator=gen, dtype=torch.float64)
+    ll, lh, hl, hh = _HaarDWT()(x)
+    ref = torch.cat([ll, torch.cat([lh, hl, hh], 1).mean(1, keepdim=True)], 1)
+    ref.backward(g)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    w, b = torch.randn(1, 3 * C, 1, 1, device=DEV, requires_grad=True), torch.randn(1, device=DEV, requires_grad=True)
+    out = ops.iwp_front(xd, w, b)
+    out.backward(g.float().to(DEV))
+    _report("iwp_front %s" % ((B, C, H, W),), out=rel_err(out, ref), dx=rel_err(xd.grad, x.grad))
+    assert float(w.grad.abs().max()) == 0.0 and float(b.grad.abs().max()) == 0.0      # softmax over one channel
+
+
 def test_colsum_multi_vs_torch():
     """csrc/colsum.hip: ragged row / column counts, 1..8 arrays per launch, deterministic."""
     ops = _ops()
