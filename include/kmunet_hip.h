@@ -220,6 +220,39 @@ int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbi
                           int Co, int P, int act_in, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * DirectionAttention's  conv(attn) * gate  (KM_UNetV3_SH.py:262-263): depthwise 3x3 with a per-(b,c) plane scale folded
+ * into the epilogue, y = scale[b,c] * (dwconv3x3(x) + bias).  Backward: dx = scaled_bwd_data(dy); run
+ * kmu_dwconv3x3_bwd_weight on the UNSCALED dy, then scaled_finish turns its partials into d_weight [C,9], d_bias [C]
+ * and d_scale [B,C].
+ * ------------------------------------------------------------------------------------ */
+int kmu_dwconv3x3_scaled_fwd(const float* x, const float* weight, const float* bias, const float* scale, float* y, int B, int C,
+                             int H, int W, kmu_stream_t stream);
+int kmu_dwconv3x3_scaled_bwd_data(const float* dy, const float* weight, const float* scale, float* dx, int B, int C, int H, int W,
+                                  kmu_stream_t stream);
+int kmu_dwconv3x3_scaled_finish(const float* d_weight_partial, const float* d_bias_partial, const float* scale,
+                                const float* weight, const float* bias, float* d_weight, float* d_bias, float* d_scale, int B,
+                                int C, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Separable 11-tap window filter of HybridLoss's SSIM term (train_shanghai.py:298-325; torchmetrics SSIM defaults:
+ * gaussian 11x11, sigma 1.5) over N planes [H,W]: adjoint = 0 -> 'valid' filter, out [N,H-10,W-10];
+ * adjoint = 1 -> its transpose (input gradient), out [N,H+10,W+10].  taps: 11 floats on the device.
+ * ------------------------------------------------------------------------------------ */
+int kmu_gauss11_filter(const float* in, const float* taps, float* out, int N, int H, int W, int adjoint, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * EnhancedViMBlock's branch fusion + DropPath + residual (KM_UNetV3_SH.py:141-146):
+ *   out[b] = x[b] + s[b] * (g[b,0] f0[b] + g[b,1] f1[b] + g[b,2] f2[b]),   g [B,3], s [B] or NULL (= 1).
+ * bwd: d_f_i = s g_i dy (dx == dy: nothing to compute); d_g_partial [kmu_mix3_blocks(n)][B*3] per-block partial dot
+ * products, to be column-summed (kmu_colsum_multi) into d_g [B,3].  n_per_sample = C*H*W, a multiple of 4.
+ * ------------------------------------------------------------------------------------ */
+int kmu_mix3_blocks(int n_per_sample);
+int kmu_mix3_fwd(const float* x, const float* f0, const float* f1, const float* f2, const float* g, const float* s, float* out,
+                 int B, int n_per_sample, kmu_stream_t stream);
+int kmu_mix3_bwd(const float* dy, const float* f0, const float* f1, const float* f2, const float* g, const float* s, float* d_f0,
+                 float* d_f1, float* d_f2, float* d_g_partial, int B, int n_per_sample, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * IntelligentWaveletPoolingModule up to its fusion conv (WPL/iwp.py:124-130; Haar DWT_2D iwp.py:47-113):
  * x [B,C,H,W] (H, W even) -> out [B,C+1,H/2,W/2] = cat[LL, mean over the 3C channels of cat[LH,HL,HH]].  The
  * Softmax2d attention over one channel (iwp.py:127) is identically 1, its conv receives an exactly-zero gradient.

@@ -49,6 +49,13 @@ SIGNATURES = {
     "kmu_pwconv_bwd_input": (_I, [_P] * 4 + [_I] * 5 + [_P]),
     "kmu_pwconv_bwd_weight_ws_bytes": (_Z, [_I] * 4),
     "kmu_pwconv_bwd_weight": (_I, [_P] * 5 + [_Z] + [_I] * 5 + [_P]),
+    "kmu_dwconv3x3_scaled_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "kmu_dwconv3x3_scaled_bwd_data": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "kmu_dwconv3x3_scaled_finish": (_I, [_P] * 8 + [_I] * 2 + [_P]),
+    "kmu_gauss11_filter": (_I, [_P] * 3 + [_I] * 4 + [_P]),
+    "kmu_mix3_blocks": (_I, [_I]),
+    "kmu_mix3_fwd": (_I, [_P] * 7 + [_I] * 2 + [_P]),
+    "kmu_mix3_bwd": (_I, [_P] * 10 + [_I] * 2 + [_P]),
     "kmu_iwp_front_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_iwp_front_bwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_gate_mlp_fwd": (_I, [_P] * 7 + [_I] * 6 + [_P]),

@@ -30,6 +30,8 @@ SOURCES = [
     ("colsum.hip", []),
     ("gate_mlp.hip", []),
     ("iwp.hip", []),
+    ("gauss11.hip", []),
+    ("mix3.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -19,8 +19,8 @@ namespace {
 constexpr int WSPLIT = 4;  // row splits per (b, c) plane in the weight-gradient kernel
 
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ out, int C,
-                                                        int H, int W, int flip, size_t total) {
+                                                        const float* __restrict__ bias, const float* __restrict__ scale,
+                                                        float* __restrict__ out, int C, int H, int W, int flip, size_t total) {
     const int W4 = (W + 3) >> 2;
     const bool vec_ok = (W & 3) == 0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -57,6 +57,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) acc[q] += wv[dy * 3 + dx] * v[q + dx];
+        }
+        if (scale) {                        // per-(b, c) plane gate, r == b*C + c
+            const float sc = scale[r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] *= sc;
         }
         float* dst = out + (r * H + y) * (size_t)W + x0;
         if (vec_ok) {
@@ -135,12 +140,53 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const float* 
     }
 }
 
-int launch_stencil(const float* in, const float* w, const float* bias, float* out, int B, int C, int H, int W, int flip,
-                   hipStream_t st, const char* what) {
+// With y = s[b,c] * (conv(x) + bias) the per-(b, row-split, c) partials A[.,t] = sum dy*x_shift_t, G = sum dy of the
+// weight-gradient kernel (dy unscaled) give everything:   dw[c,t] = sum_b s[b,c] A[b,c,t],   db[c] = sum_b s[b,c] G[b,c],
+// ds[b,c] = sum_t w[c,t] A[b,c,t] + bias[c] G[b,c]   (fixed summation order).
+__global__ __launch_bounds__(256) void dwconv3x3_scaled_finish_kernel(const float* __restrict__ dw_part, const float* __restrict__ db_part,
+                                                                      const float* __restrict__ scale, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias, float* __restrict__ dw,
+                                                                      float* __restrict__ db, float* __restrict__ dscale, int B, int C) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < C * 9) {
+        const int c = t / 9;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float a = 0.f;
+            for (int sp = 0; sp < WSPLIT; ++sp) a += dw_part[((size_t)(b * WSPLIT + sp) * C) * 9 + t];
+            s += scale[b * C + c] * a;
+        }
+        dw[t] = s;
+    } else if (t < C * 10) {
+        const int c = t - C * 9;
+        if (db) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) {
+                float g = 0.f;
+                for (int sp = 0; sp < WSPLIT; ++sp) g += db_part[(size_t)(b * WSPLIT + sp) * C + c];
+                s += scale[b * C + c] * g;
+            }
+            db[c] = s;
+        }
+    } else if (t < C * 10 + B * C) {
+        const int e = t - C * 10, b = e / C, c = e - b * C;
+        float s = 0.f;
+        for (int sp = 0; sp < WSPLIT; ++sp) {
+            const float* a = dw_part + ((size_t)(b * WSPLIT + sp) * C + c) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s += w[c * 9 + k] * a[k];
+            if (bias) s += bias[c] * db_part[(size_t)(b * WSPLIT + sp) * C + c];
+        }
+        dscale[e] = s;
+    }
+}
+
+int launch_stencil(const float* in, const float* w, const float* bias, const float* scale, float* out, int B, int C, int H, int W,
+                   int flip, hipStream_t st, const char* what) {
     const size_t total = (size_t)B * C * H * ((W + 3) / 4);
     size_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, out, C, H, W, flip, total);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, scale, out, C, H, W, flip, total);
     return kmu::launch_status(what);
 }
 
@@ -150,14 +196,14 @@ extern "C" int kmu_dwconv3x3_fwd(const float* x, const float* weight, const floa
                                  int W, kmu_stream_t stream) {
     KMU_REQUIRE(x && weight && y, "dwconv3x3_fwd: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_fwd: bad dims");
-    return launch_stencil(x, weight, bias, y, B, C, H, W, 0, (hipStream_t)stream, "dwconv3x3_fwd");
+    return launch_stencil(x, weight, bias, nullptr, y, B, C, H, W, 0, (hipStream_t)stream, "dwconv3x3_fwd");
 }
 
 extern "C" int kmu_dwconv3x3_bwd_data(const float* dy, const float* weight, float* dx, int B, int C, int H, int W,
                                       kmu_stream_t stream) {
     KMU_REQUIRE(dy && weight && dx, "dwconv3x3_bwd_data: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_bwd_data: bad dims");
-    return launch_stencil(dy, weight, nullptr, dx, B, C, H, W, 1, (hipStream_t)stream, "dwconv3x3_bwd_data");
+    return launch_stencil(dy, weight, nullptr, nullptr, dx, B, C, H, W, 1, (hipStream_t)stream, "dwconv3x3_bwd_data");
 }
 
 extern "C" int kmu_dwconv3x3_partials(int B) { return B * WSPLIT; }
@@ -169,4 +215,30 @@ extern "C" int kmu_dwconv3x3_bwd_weight(const float* x, const float* dy, float* 
     hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(C, B, WSPLIT), dim3(256), 0, (hipStream_t)stream, x, dy,
                        d_weight_partial, d_bias_partial, C, H, W);
     return kmu::launch_status("dwconv3x3_bwd_weight");
+}
+
+extern "C" int kmu_dwconv3x3_scaled_fwd(const float* x, const float* weight, const float* bias, const float* scale, float* y, int B,
+                                        int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && weight && scale && y, "dwconv3x3_scaled_fwd: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_scaled_fwd: bad dims");
+    return launch_stencil(x, weight, bias, scale, y, B, C, H, W, 0, (hipStream_t)stream, "dwconv3x3_scaled_fwd");
+}
+
+extern "C" int kmu_dwconv3x3_scaled_bwd_data(const float* dy, const float* weight, const float* scale, float* dx, int B, int C, int H,
+                                             int W, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && weight && scale && dx, "dwconv3x3_scaled_bwd_data: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_scaled_bwd_data: bad dims");
+    return launch_stencil(dy, weight, nullptr, scale, dx, B, C, H, W, 1, (hipStream_t)stream, "dwconv3x3_scaled_bwd_data");
+}
+
+extern "C" int kmu_dwconv3x3_scaled_finish(const float* d_weight_partial, const float* d_bias_partial, const float* scale,
+                                           const float* weight, const float* bias, float* d_weight, float* d_bias, float* d_scale,
+                                           int B, int C, kmu_stream_t stream) {
+    KMU_REQUIRE(d_weight_partial && d_bias_partial && scale && weight && d_weight && d_scale, "dwconv3x3_scaled_finish: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0, "dwconv3x3_scaled_finish: bad dims");
+    KMU_REQUIRE((bias == nullptr) == (d_bias == nullptr), "dwconv3x3_scaled_finish: bias and d_bias must both be given or both be NULL");
+    const int threads = C * 10 + B * C;
+    hipLaunchKernelGGL(dwconv3x3_scaled_finish_kernel, dim3(kmu::cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, d_weight_partial,
+                       d_bias_partial, scale, weight, bias, d_weight, d_bias, d_scale, B, C);
+    return kmu::launch_status("dwconv3x3_scaled_finish");
 }

@@ -1,0 +1,91 @@
+// EnhancedViMBlock's branch fusion (KM_UNetV3_SH.py:141-146):
+//     out[b] = x[b] + s[b] * (g[b,0] f0[b] + g[b,1] f1[b] + g[b,2] f2[b])
+// g = softmax fusion weights [B,3], s = DropPath's per-sample mask / keep_prob (NULL = 1).  Stock ATen: 3 mul + 2 add
+// + mul + add forward, ~12 launches backward; here one streaming kernel each way (backward also leaves the per-block
+// partial dot products for d g).  HBM-bound: forward reads 4 and writes 1 tensor, backward reads 4 and writes 3.
+#include "common.h"
+
+using kmu::floatx4;
+
+namespace {
+
+constexpr int VPT = 4;   // float4s per thread => 4096 floats per 256-thread block
+
+__global__ __launch_bounds__(256) void mix3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ f0,
+                                                       const float* __restrict__ f1, const float* __restrict__ f2,
+                                                       const float* __restrict__ g, const float* __restrict__ s, float* __restrict__ out,
+                                                       int n4) {
+    const int b = blockIdx.y;
+    const float sc = s ? s[b] : 1.f;
+    const float k0 = sc * g[b * 3], k1 = sc * g[b * 3 + 1], k2 = sc * g[b * 3 + 2];
+    const size_t base = (size_t)b * n4;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int i = (blockIdx.x * VPT + v) * 256 + threadIdx.x;
+        if (i >= n4) break;
+        const floatx4 xv = reinterpret_cast<const floatx4*>(x)[base + i], a = reinterpret_cast<const floatx4*>(f0)[base + i],
+                      bb = reinterpret_cast<const floatx4*>(f1)[base + i], c = reinterpret_cast<const floatx4*>(f2)[base + i];
+        reinterpret_cast<floatx4*>(out)[base + i] = xv + k0 * a + k1 * bb + k2 * c;
+    }
+}
+
+// df_i = (s g_i) dy ;  part[blockIdx.x][b*3 + i] = s * sum_block dy . f_i
+__global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ f0,
+                                                       const float* __restrict__ f1, const float* __restrict__ f2,
+                                                       const float* __restrict__ g, const float* __restrict__ s, float* __restrict__ d0,
+                                                       float* __restrict__ d1, float* __restrict__ d2, float* __restrict__ part, int n4,
+                                                       int B) {
+    __shared__ float red[4][3];
+    const int b = blockIdx.y;
+    const float sc = s ? s[b] : 1.f;
+    const float k0 = sc * g[b * 3], k1 = sc * g[b * 3 + 1], k2 = sc * g[b * 3 + 2];
+    const size_t base = (size_t)b * n4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int i = (blockIdx.x * VPT + v) * 256 + threadIdx.x;
+        if (i >= n4) break;
+        const floatx4 gy = reinterpret_cast<const floatx4*>(dy)[base + i], a = reinterpret_cast<const floatx4*>(f0)[base + i],
+                      bb = reinterpret_cast<const floatx4*>(f1)[base + i], c = reinterpret_cast<const floatx4*>(f2)[base + i];
+        reinterpret_cast<floatx4*>(d0)[base + i] = k0 * gy;
+        reinterpret_cast<floatx4*>(d1)[base + i] = k1 * gy;
+        reinterpret_cast<floatx4*>(d2)[base + i] = k2 * gy;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0 += gy[q] * a[q];
+            a1 += gy[q] * bb[q];
+            a2 += gy[q] * c[q];
+        }
+    }
+    a0 = kmu::wave_sum(a0), a1 = kmu::wave_sum(a1), a2 = kmu::wave_sum(a2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave][0] = a0, red[wave][1] = a1, red[wave][2] = a2;
+    __syncthreads();
+    if (threadIdx.x < 3)
+        part[(size_t)blockIdx.x * B * 3 + b * 3 + threadIdx.x] =
+            sc * ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+}  // namespace
+
+extern "C" int kmu_mix3_blocks(int n_per_sample) { return n_per_sample > 0 ? kmu::cdiv(n_per_sample / 4, 256 * VPT) : 0; }
+
+extern "C" int kmu_mix3_fwd(const float* x, const float* f0, const float* f1, const float* f2, const float* g, const float* s, float* out,
+                            int B, int n_per_sample, kmu_stream_t stream) {
+    KMU_REQUIRE(x && f0 && f1 && f2 && g && out, "mix3_fwd: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_fwd: C*H*W = %d must be a positive multiple of 4",
+                n_per_sample);
+    hipLaunchKernelGGL(mix3_fwd_kernel, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, x, f0, f1, f2, g, s, out,
+                       n_per_sample / 4);
+    return kmu::launch_status("mix3_fwd");
+}
+
+extern "C" int kmu_mix3_bwd(const float* dy, const float* f0, const float* f1, const float* f2, const float* g, const float* s, float* d_f0,
+                            float* d_f1, float* d_f2, float* d_g_partial, int B, int n_per_sample, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && f0 && f1 && f2 && g && d_f0 && d_f1 && d_f2 && d_g_partial, "mix3_bwd: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_bwd: C*H*W = %d must be a positive multiple of 4",
+                n_per_sample);
+    hipLaunchKernelGGL(mix3_bwd_kernel, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, dy, f0, f1, f2, g, s, d_f0,
+                       d_f1, d_f2, d_g_partial, n_per_sample / 4, B);
+    return kmu::launch_status("mix3_bwd");
+}

@@ -41,9 +41,15 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
+        return x * self.scale(x).view(-1, 1, 1, 1)
+
+    def scale(self, x):
+        """Per-sample factor mask / keep_prob [B] for this call, or None when the layer is the identity."""
+        if self.drop_prob == 0.0 or not self.training:
+            return None
         keep = 1.0 - self.drop_prob
-        mask = torch.empty(x.shape[0], 1, 1, 1, device=x.device, dtype=x.dtype).bernoulli_(keep)
-        return x * (mask / keep if self.scale_by_keep else mask)
+        mask = torch.empty(x.shape[0], device=x.device, dtype=x.dtype).bernoulli_(keep)
+        return mask / keep if self.scale_by_keep else mask
 
 
 class StableHybridKANConv(nn.Module):
@@ -92,7 +98,7 @@ class DirectionAttention(nn.Module):
             attn = torch.sigmoid(q * k) * v
         if "dwconv" in _TORCH_GLUE:
             return self.conv(attn) * gate.view(b, c, 1, 1)
-        return ops.dwconv3x3(attn, self.conv.weight, self.conv.bias) * gate.view(b, c, 1, 1)
+        return ops.dwconv3x3_scaled(attn, self.conv.weight, self.conv.bias, gate)     # gate folded into the stencil's epilogue
 
 
 class DirectionViM(nn.Module):
@@ -174,10 +180,16 @@ class EnhancedViMBlock(nn.Module):
         feats = self._branches(x)
         # fusion_gate = pool . conv1x1 . GELU . conv1x1 . softmax: pooling commutes with the channel concat
         pooled = torch.cat([f.mean(dim=(2, 3)) for f in feats], dim=1)
-        g = gate_mlp(pooled, self.fusion_gate[1], self.fusion_gate[3], "gelu", "softmax")[:, :, None, None]
-        x = x + self.drop_path(g[:, 0:1] * feats[0] + g[:, 1:2] * feats[1] + g[:, 2:3] * feats[2])
+        g = gate_mlp(pooled, self.fusion_gate[1], self.fusion_gate[3], "gelu", "softmax")
+        dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
+        if "mix3" in _TORCH_GLUE or not x.is_cuda:
+            g = g[:, :, None, None]
+            x = x + self.drop_path(g[:, 0:1] * feats[0] + g[:, 1:2] * feats[1] + g[:, 2:3] * feats[2])
+        else:       # weighted branch sum + DropPath + residual: one HIP kernel (csrc/mix3.hip)
+            x = ops.mix3(x, feats[0], feats[1], feats[2], g, dp.scale(x) if dp is not None else None)
         f = conv1x1(conv1x1(self.norm(x), self.ffn[0]), self.ffn[2], gelu_in=True)   # GELU folded into ffn[2]'s load
-        return x + self.drop_path(f)
+        s = dp.scale(x) if dp is not None else None
+        return x + f if s is None else torch.addcmul(x, f, s.view(-1, 1, 1, 1))
 
 
 class ChannelAttention(nn.Module):

@@ -384,6 +384,123 @@ def dwconv3x3(x, weight, bias=None):
     return DwConv3x3Fn.apply(x, weight, bias)
 
 
+class DwConv3x3ScaledFn(torch.autograd.Function):
+    """y = scale[b,c] * (depthwise3x3(x) + bias): DirectionAttention's conv(attn) * gate (KM_UNetV3_SH.py:262-263)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale):
+        lib = _lib.load()
+        x, w = _f32c(x, "x"), _f32c(weight, "weight")
+        b = None if bias is None else _f32c(bias, "bias")
+        B, C, H, W = x.shape
+        sc = _f32c(scale, "scale").view(B, C)
+        y = torch.empty_like(x)
+        _lib.check(_call(("dwconv3x3_scaled_fwd", (B, C, H, W)), lib.kmu_dwconv3x3_scaled_fwd, _ptr(x), _ptr(w), _ptr(b), _ptr(sc), _ptr(y),
+                         B, C, H, W, _stream()), "kmu_dwconv3x3_scaled_fwd")
+        ctx.save_for_backward(x, w, b, sc)
+        ctx.sshape = scale.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, b, sc = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B, C, H, W = x.shape
+        st, dev = _stream(), x.device
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(_call(("dwconv3x3_scaled_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_scaled_bwd_data, _ptr(dy), _ptr(w), _ptr(sc),
+                             _ptr(dx), B, C, H, W, st), "kmu_dwconv3x3_scaled_bwd_data")
+        P = lib.kmu_dwconv3x3_partials(B)
+        dwp = torch.empty(P, C, 9, device=dev, dtype=torch.float32)
+        dbp = torch.empty(P, C, device=dev, dtype=torch.float32)
+        _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dy), _ptr(dwp), _ptr(dbp), B, C,
+                         H, W, st), "kmu_dwconv3x3_bwd_weight")
+        dw = torch.empty(C, 1, 3, 3, device=dev, dtype=torch.float32)
+        db = torch.empty(C, device=dev, dtype=torch.float32) if b is not None else None
+        ds = torch.empty(B, C, device=dev, dtype=torch.float32)
+        _lib.check(_call(("dwconv3x3_scaled_finish", (B, C)), lib.kmu_dwconv3x3_scaled_finish, _ptr(dwp), _ptr(dbp), _ptr(sc), _ptr(w),
+                         _ptr(b), _ptr(dw), _ptr(db), _ptr(ds), B, C, st), "kmu_dwconv3x3_scaled_finish")
+        return dx, dw, db, ds.view(ctx.sshape)
+
+
+def dwconv3x3_scaled(x, weight, bias, scale):
+    return DwConv3x3ScaledFn.apply(x, weight, bias, scale)
+
+
+# ------------------------------------------------------------------------------------------ branch fusion
+class Mix3Fn(torch.autograd.Function):
+    """out = x + s[b] * (g[b,0] f0 + g[b,1] f1 + g[b,2] f2)  (KM_UNetV3_SH.py:141-146); s = DropPath scale or None."""
+
+    @staticmethod
+    def forward(ctx, x, f0, f1, f2, g, s):
+        lib = _lib.load()
+        x, f0, f1, f2 = _f32c(x, "x"), _f32c(f0, "f0"), _f32c(f1, "f1"), _f32c(f2, "f2")
+        B = x.shape[0]
+        n = x.numel() // B
+        gc = _f32c(g, "g").view(B, 3)
+        sc = None if s is None else _f32c(s, "s").view(B)
+        out = torch.empty_like(x)
+        _lib.check(_call(("mix3_fwd", (B, n)), lib.kmu_mix3_fwd, _ptr(x), _ptr(f0), _ptr(f1), _ptr(f2), _ptr(gc), _ptr(sc), _ptr(out), B, n,
+                         _stream()), "kmu_mix3_fwd")
+        ctx.save_for_backward(f0, f1, f2, gc, sc)
+        ctx.gshape = g.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        f0, f1, f2, gc, sc = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B = dy.shape[0]
+        n = dy.numel() // B
+        d0, d1, d2 = torch.empty_like(f0), torch.empty_like(f1), torch.empty_like(f2)
+        part = torch.empty(lib.kmu_mix3_blocks(n), B * 3, device=dy.device, dtype=torch.float32)
+        _lib.check(_call(("mix3_bwd", (B, n)), lib.kmu_mix3_bwd, _ptr(dy), _ptr(f0), _ptr(f1), _ptr(f2), _ptr(gc), _ptr(sc), _ptr(d0),
+                         _ptr(d1), _ptr(d2), _ptr(part), B, n, _stream()), "kmu_mix3_bwd")
+        (dg,) = colsum(part)
+        return dy, d0, d1, d2, dg.view(ctx.gshape), None
+
+
+def mix3(x, f0, f1, f2, g, s=None):
+    return Mix3Fn.apply(x, f0, f1, f2, g, s)
+
+
+# ------------------------------------------------------------------------------------------ SSIM window filter
+class Gauss11Fn(torch.autograd.Function):
+    """'valid' separable 11-tap filter over the last two dims (HybridLoss's SSIM window); backward = its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, taps):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        H, W = x.shape[-2:]
+        N = x.numel() // (H * W)
+        out = torch.empty(*x.shape[:-2], H - 10, W - 10, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("gauss11_filter", (N, H, W)), lib.kmu_gauss11_filter, _ptr(x), _ptr(taps), _ptr(out), N, H, W, 0, _stream()),
+                   "kmu_gauss11_filter")
+        ctx.save_for_backward(taps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (taps,) = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        H, W = g.shape[-2:]
+        N = g.numel() // (H * W)
+        dx = torch.empty(*g.shape[:-2], H + 10, W + 10, device=g.device, dtype=torch.float32)
+        _lib.check(_call(("gauss11_adjoint", (N, H, W)), lib.kmu_gauss11_filter, _ptr(g), _ptr(taps), _ptr(dx), N, H, W, 1, _stream()),
+                   "kmu_gauss11_filter")
+        return dx, None
+
+
+def gauss11(x, taps):
+    return Gauss11Fn.apply(x, taps)
+
+
 # ------------------------------------------------------------------------------------------ BN + ReLU + blend
 class BnBlendFn(torch.autograd.Function):
     """out = x + sigmoid(alpha[row]) * (f(t) - x),  f = relu?(BatchNorm2d(t)) or identity

@@ -404,6 +404,68 @@ def test_iwp_front_vs_slicing(B, C, H, W):
     assert float(w.grad.abs().max()) == 0.0 and float(b.grad.abs().max()) == 0.0      # softmax over one channel
 
 
+@pytest.mark.parametrize("B,C,H,W,bias", [(2, 16, 16, 16, True), (3, 5, 7, 9, False), (8, 64, 32, 32, True)])
+def test_dwconv3x3_scaled_vs_torch_cpu(B, C, H, W, bias):
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
+    x, w, sc = mk(B, C, H, W), mk(C, 1, 3, 3), mk(B, C)
+    bv = mk(C) if bias else None
+    gy = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64)
+    yo = F.conv2d(x, w, bv, padding=1, groups=C) * sc.view(B, C, 1, 1)
+    yo.backward(gy)
+    dev = lambda t: None if t is None else t.detach().float().to(DEV).requires_grad_(True)
+    xd, wd, bd, sd = dev(x), dev(w), dev(bv), dev(sc)
+    y = ops.dwconv3x3_scaled(xd, wd, bd, sd)
+    y.backward(gy.float().to(DEV))
+    errs = dict(y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad), dw=rel_err(wd.grad, w.grad), dscale=rel_err(sd.grad, sc.grad))
+    if bias:
+        errs["db"] = rel_err(bd.grad, bv.grad)
+    _report("dwconv3x3_scaled %s" % ((B, C, H, W, bias),), **errs)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 20, 33), (1, 1, 11, 11), (40, 5, 138, 138)])
+def test_gauss11_vs_torch_cpu(shape):
+    """csrc/gauss11.hip against F.conv2d with the outer-product window (fp64, CPU), forward and adjoint."""
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(shape[-1])
+    dist = torch.arange(-5, 6, dtype=torch.float64)
+    g = torch.exp(-((dist / 1.5) ** 2) / 2)
+    g = g / g.sum()
+    x = torch.randn(*shape, generator=gen, dtype=torch.float64).requires_grad_(True)
+    c = shape[1]
+    yo = F.conv2d(x, torch.outer(g, g).expand(c, 1, 11, 11), groups=c)
+    gy = torch.randn(*yo.shape, generator=gen, dtype=torch.float64)
+    yo.backward(gy)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    y = ops.gauss11(xd, g.float().to(DEV))
+    y.backward(gy.float().to(DEV))
+    _report("gauss11 %s" % (shape,), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad))
+
+
+@pytest.mark.parametrize("B,C,H,W,drop", [(8, 16, 32, 32, True), (3, 5, 6, 10, False), (2, 64, 16, 16, True)])
+def test_mix3_vs_torch_cpu(B, C, H, W, drop):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C * H)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
+    x, f0, f1, f2 = mk(B, C, H, W), mk(B, C, H, W), mk(B, C, H, W), mk(B, C, H, W)
+    g = torch.softmax(torch.randn(B, 3, generator=gen, dtype=torch.float64), 1).requires_grad_(True)
+    s = (torch.rand(B, generator=gen, dtype=torch.float64) > 0.3).double() / 0.7 if drop else None
+    gy = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64)
+    gv = g[:, :, None, None]
+    mix = gv[:, 0:1] * f0 + gv[:, 1:2] * f1 + gv[:, 2:3] * f2
+    yo = x + (mix if s is None else mix * s.view(B, 1, 1, 1))
+    yo.backward(gy)
+    dev = lambda t: None if t is None else t.detach().float().to(DEV).requires_grad_(True)
+    xd, a, b, c, gd = dev(x), dev(f0), dev(f1), dev(f2), dev(g)
+    y = ops.mix3(xd, a, b, c, gd, None if s is None else s.float().to(DEV))
+    y.backward(gy.float().to(DEV))
+    _report("mix3 %s" % ((B, C, H, W, drop),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad), df0=rel_err(a.grad, f0.grad),
+            df1=rel_err(b.grad, f1.grad), df2=rel_err(c.grad, f2.grad), dg=rel_err(gd.grad, g.grad))
+
+
 def test_colsum_multi_vs_torch():
     """csrc/colsum.hip: ragged row / column counts, 1..8 arrays per launch, deterministic."""
     ops = _ops()
