@@ -94,9 +94,9 @@ int kmu_kan_conv2d_bwd_weights(const float* x, const float* dy, const float* kno
 int kmu_layernorm1d_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean /*[B,L,2]*/,
                         int B, int C, int L, float eps, kmu_stream_t stream);
 int kmu_layernorm1d_bwd(const float* x, const float* weight, const float* rstd_mean, const float* dy, float* dx,
-                        float* d_weight_partial /*[B*ceil(L/256),C]*/, float* d_bias_partial, int B, int C, int L,
-                        kmu_stream_t stream);
-int kmu_layernorm1d_partials(int B, int L); /* rows of the *_partial outputs */
+                        float* d_weight_partial /*[kmu_layernorm1d_partials(B,C,L), C]*/, float* d_bias_partial, int B, int C,
+                        int L, kmu_stream_t stream);
+int kmu_layernorm1d_partials(int B, int C, int L); /* rows of the *_partial outputs */
 
 size_t kmu_hsmssd_state_elems(int B, int C, int N);
 size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs);

@@ -26,7 +26,7 @@ SIGNATURES = {
     "kmu_kan_conv2d_bwd_weights": (_I, [_P] * 9 + [_Z] + [_I] * 5 + [_P]),
     "kmu_layernorm1d_fwd": (_I, [_P] * 5 + [_I] * 3 + [_c.c_float, _P]),
     "kmu_layernorm1d_bwd": (_I, [_P] * 7 + [_I] * 3 + [_P]),
-    "kmu_layernorm1d_partials": (_I, [_I, _I]),
+    "kmu_layernorm1d_partials": (_I, [_I, _I, _I]),
     "kmu_hsmssd_state_elems": (_Z, [_I] * 3),
     "kmu_hsmssd_fwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_hsmssd_fwd": (_I, [_P] * 10 + [_Z] + [_I] * 4 + [_P]),

@@ -457,6 +457,145 @@ __global__ __launch_bounds__(256) void ln1d_bwd_kernel(const float* __restrict__
     }
 }
 
+// Register-resident variants for the channel counts KM-UNet uses: a thread owns V consecutive tokens (V-wide loads,
+// every element read exactly once), x / dy stay in registers between the statistics and the output pass, and the
+// parameter-gradient partials need one block reduction per kernel instead of one per channel.
+template <int V>
+struct VecOf;
+template <>
+struct VecOf<1> { typedef float T; };
+template <>
+struct VecOf<2> { typedef floatx2 T; };
+template <>
+struct VecOf<4> { typedef floatx4 T; };
+template <int V>
+__device__ __forceinline__ void ldv(float (&dst)[V], const float* p) {
+    typename VecOf<V>::T t = *reinterpret_cast<const typename VecOf<V>::T*>(p);
+    if constexpr (V == 1) dst[0] = t;
+    else
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = t[i];
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const float (&src)[V]) {
+    typename VecOf<V>::T t;
+    if constexpr (V == 1) t = src[0];
+    else
+#pragma unroll
+        for (int i = 0; i < V; ++i) t[i] = src[i];
+    *reinterpret_cast<typename VecOf<V>::T*>(p) = t;
+}
+
+template <int C, int V>
+__global__ __launch_bounds__(256) void ln1d_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           float* __restrict__ stats, int L, float eps) {
+    const int b = blockIdx.y, l0 = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (l0 >= L) return;
+    const size_t base = (size_t)b * C * L + l0;
+    float v[C][V], mu[V], rstd[V];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ldv<V>(v[c], x + base + (size_t)c * L);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) m += v[c][i];
+        m /= (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float d = v[c][i] - m;
+            var += d * d;
+        }
+        var /= (float)C;
+        mu[i] = m;
+        rstd[i] = 1.f / sqrtf(var + eps);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float wc = w[c], bc = bias[c];
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = (v[c][i] - mu[i]) * rstd[i] * wc + bc;
+        stv<V>(y + base + (size_t)c * L, o);
+    }
+    float* sp = stats + ((size_t)b * L + l0) * 2;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        sp[2 * i] = rstd[i];
+        sp[2 * i + 1] = mu[i];
+    }
+}
+
+template <int C, int V>
+__global__ __launch_bounds__(256) void ln1d_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ stats, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, float* __restrict__ dw_part,
+                                                           float* __restrict__ db_part, int L) {
+    __shared__ float red[2 * C][4];
+    const int b = blockIdx.y, l0 = (blockIdx.x * 256 + threadIdx.x) * V;
+    const bool ok = l0 < L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = (size_t)b * C * L + (ok ? l0 : 0);
+    float gdw[C], gdb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gdw[c] = gdb[c] = 0.f;
+    if (ok) {
+        float xh[C][V], g[C][V], rstd[V], s1[V], s2[V];
+        const float* sp = stats + ((size_t)b * L + l0) * 2;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            ldv<V>(xh[c], x + base + (size_t)c * L);
+            ldv<V>(g[c], dy + base + (size_t)c * L);
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            rstd[i] = sp[2 * i];
+            const float mu = sp[2 * i + 1];
+            s1[i] = s2[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                xh[c][i] = (xh[c][i] - mu) * rstd[i];
+                gdw[c] += g[c][i] * xh[c][i];
+                gdb[c] += g[c][i];
+                const float gw = g[c][i] * w[c];
+                s1[i] += gw;
+                s2[i] += gw * xh[c][i];
+            }
+            s1[i] /= (float)C;
+            s2[i] /= (float)C;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float wc = w[c];
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) o[i] = rstd[i] * (g[c][i] * wc - s1[i] - xh[c][i] * s2[i]);
+            stv<V>(dx + base + (size_t)c * L, o);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float a = kmu::wave_sum(gdw[c]), d = kmu::wave_sum(gdb[c]);
+        if (lane == 0) {
+            red[c][wave] = a;
+            red[C + c][wave] = d;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        const int c = threadIdx.x % C;
+        const float s = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        const size_t prow = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        (threadIdx.x < C ? dw_part : db_part)[prow * C + c] = s;
+    }
+}
+
+// tokens per thread of the register variants (0 = generic kernels): forward keeps C*V = 64 values, backward 2 x 32
+inline int ln1d_vf(int C, int L) { return (C == 16 && L % 4 == 0) ? 4 : (C == 32 && L % 2 == 0) ? 2 : (C == 64 ? 1 : 0); }
+inline int ln1d_vb(int C, int L) { return (C == 16 && L % 2 == 0) ? 2 : ((C == 32 || C == 64) ? 1 : 0); }
+
 // ---------------------------------------------------------------------------------------------
 template <int C>
 size_t lds_pass1() {
@@ -543,14 +682,26 @@ extern "C" int kmu_hsmssd_fwd_stage(const float* x, const float* w_bcdt, const f
     return hsmssd_fwd_stages(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream);
 }
 
-extern "C" int kmu_layernorm1d_partials(int B, int L) { return B * kmu::cdiv(L, 256); }
+extern "C" int kmu_layernorm1d_partials(int B, int C, int L) {
+    const int V = ln1d_vb(C, L);
+    return B * kmu::cdiv(L, 256 * (V ? V : 1));
+}
 
 extern "C" int kmu_layernorm1d_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean,
                                    int B, int C, int L, float eps, kmu_stream_t stream) {
     KMU_REQUIRE(x && weight && bias && y && rstd_mean, "layernorm1d_fwd: null pointer");
     KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0, "layernorm1d_fwd: bad dims");
-    hipLaunchKernelGGL(ln1d_fwd_kernel, dim3(kmu::cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, x, weight, bias, y,
-                       rstd_mean, C, L, eps);
+    hipStream_t st = (hipStream_t)stream;
+    const int V = ln1d_vf(C, L);
+    const dim3 grid(kmu::cdiv(L, 256 * (V ? V : 1)), B);
+    if (C == 16 && V == 4)
+        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<16, 4>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps);
+    else if (C == 32 && V == 2)
+        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<32, 2>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps);
+    else if (C == 64 && V == 1)
+        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<64, 1>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps);
+    else
+        hipLaunchKernelGGL(ln1d_fwd_kernel, grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, C, L, eps);
     return kmu::launch_status("layernorm1d_fwd");
 }
 
@@ -559,8 +710,21 @@ extern "C" int kmu_layernorm1d_bwd(const float* x, const float* weight, const fl
                                    kmu_stream_t stream) {
     KMU_REQUIRE(x && weight && rstd_mean && dy && dx && d_weight_partial && d_bias_partial, "layernorm1d_bwd: null pointer");
     KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0, "layernorm1d_bwd: bad dims");
-    hipLaunchKernelGGL(ln1d_bwd_kernel, dim3(kmu::cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, x, weight,
-                       rstd_mean, dy, dx, d_weight_partial, d_bias_partial, C, L);
+    hipStream_t st = (hipStream_t)stream;
+    const int V = ln1d_vb(C, L);
+    const dim3 grid(kmu::cdiv(L, 256 * (V ? V : 1)), B);
+    if (C == 16 && V == 2)
+        hipLaunchKernelGGL((ln1d_bwd_reg_kernel<16, 2>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
+                           d_bias_partial, L);
+    else if (C == 32 && V == 1)
+        hipLaunchKernelGGL((ln1d_bwd_reg_kernel<32, 1>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
+                           d_bias_partial, L);
+    else if (C == 64 && V == 1)
+        hipLaunchKernelGGL((ln1d_bwd_reg_kernel<64, 1>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
+                           d_bias_partial, L);
+    else
+        hipLaunchKernelGGL(ln1d_bwd_kernel, grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial, d_bias_partial, C,
+                           L);
     return kmu::launch_status("layernorm1d_bwd");
 }
 

@@ -33,6 +33,21 @@ class FlatGradBucket:
     def zero_(self):
         self.flat.zero_()
 
+    def flatten_parameters(self):
+        """Move the parameters themselves into one contiguous buffer (`p.data` become views of it, values unchanged)
+        and return it as a leaf whose .grad is the gradient bucket: the optimizer then updates ONE tensor -- a single
+        fused AdamW launch instead of ~30 multi-tensor launches over 664 small tensors.  Uniform hyper-parameters
+        (train_shanghai.py:342 passes model.parameters() as one group), so the update is element-for-element the same."""
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self.params]) if self.params else self.flat.clone()
+            off = 0
+            for p in self.params:
+                p.data = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        flat.requires_grad_(True)
+        flat.grad = self.flat
+        return flat
+
     def store(self, grads):
         """Write one gradient per parameter into the bucket (a handful of multi-tensor copy launches)."""
         torch._foreach_copy_(self.views, list(grads))

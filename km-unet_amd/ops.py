@@ -176,7 +176,7 @@ class LayerNorm1dFn(torch.autograd.Function):
         x, w, stats = ctx.saved_tensors
         dy = _f32c(dy, "dy")
         B, C, L = x.shape
-        rows = lib.kmu_layernorm1d_partials(B, L)
+        rows = lib.kmu_layernorm1d_partials(B, C, L)
         dx = torch.empty_like(x)
         dwp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
         dbp = torch.empty(rows, C, device=x.device, dtype=torch.float32)

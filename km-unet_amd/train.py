@@ -28,7 +28,9 @@ class TrainStep:
         kw = dict(lr=lr, weight_decay=weight_decay)
         if example_data.is_cuda:
             kw.update(fused=True, capturable=capturable)
-        self.opt = torch.optim.AdamW(live, **kw)
+        # one flat parameter tensor (its .grad is the flat gradient bucket): AdamW is a single launch
+        self.flat_param = self.dp.bucket.flatten_parameters()
+        self.opt = torch.optim.AdamW([self.flat_param], **kw)
 
     def forward_backward(self, data):
         inp, tgt = split_frames(data)
