@@ -180,7 +180,8 @@ int kmu_dwconv3x3_bwd_weight(const float* x, const float* dy, float* d_weight_pa
  *     out = x + a*(f(t) - x),  a = sigmoid(alpha[c]),  f(t) = relu?(BatchNorm2d(t))   or   f(t) = t
  * t, x, out: [B,C,HW].  gamma == NULL: no BatchNorm (the mixer blend, :90).  alpha == NULL: no blend
  * (x ignored; FFN.fc1 = conv+BN+ReLU).  training != 0: batch statistics, running_mean/var updated with
- * `momentum` (unbiased variance), as nn.BatchNorm2d.  stats [C,2] = (mean, rstd) saved for backward.
+ * `momentum` (unbiased variance) and *num_batches_tracked (int64 on the device, may be NULL) incremented, as
+ * nn.BatchNorm2d.  stats [C,2] = (mean, rstd) saved for backward.
  * ws: forward [C,S,2], backward [C,S,3] floats with S = kmu_bn_blend_splits(B, HW).
  * backward: dt (and dx if blending) fully written; d_gamma/d_beta/d_alpha [C] (d_alpha is w.r.t. the RAW
  * alpha, i.e. includes sigmoid'(alpha)).
@@ -188,7 +189,8 @@ int kmu_dwconv3x3_bwd_weight(const float* x, const float* dy, float* d_weight_pa
 int kmu_bn_blend_splits(int B, int HW);
 int kmu_bn_blend_fwd(const float* t, const float* x, const float* gamma, const float* beta, const float* alpha,
                      float* running_mean, float* running_var, float momentum, float eps, int relu, int training,
-                     float* out, float* stats, float* ws, int B, int C, int HW, kmu_stream_t stream);
+                     float* out, float* stats, float* ws, long long* num_batches_tracked, int B, int C, int HW,
+                     kmu_stream_t stream);
 int kmu_bn_blend_bwd(const float* gout, const float* t, const float* x, const float* gamma, const float* beta,
                      const float* alpha, const float* stats, int relu, int training, float* dt, float* dx,
                      float* d_gamma, float* d_beta, float* d_alpha, float* ws, int B, int C, int HW,
@@ -251,6 +253,15 @@ int kmu_mix3_fwd(const float* x, const float* f0, const float* f1, const float* 
                  int B, int n_per_sample, kmu_stream_t stream);
 int kmu_mix3_bwd(const float* dy, const float* f0, const float* f1, const float* f2, const float* g, const float* s, float* d_f0,
                  float* d_f1, float* d_f2, float* d_g_partial, int B, int n_per_sample, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tap stacking for DirectionViM's (3,1) / (1,3) projections (KM_UNetV3_SH.py:170-172): x [B,C,H,W] ->
+ * out [B,3C,H,W], out[t*C + c](p) = x[c](p + (t-1) e_axis) (zero outside), axis 0 = H, 1 = W; a 3-tap conv along
+ * that axis is then kmu_pwconv_* with Ci = 3C and weight W'[co, t*C + ci] = W[co, ci, t].  bwd: dx = sum of the three
+ * shifted gradient slices.
+ * ------------------------------------------------------------------------------------ */
+int kmu_shift3_fwd(const float* x, float* out, int B, int C, int H, int W, int axis, kmu_stream_t stream);
+int kmu_shift3_bwd(const float* gout, float* dx, int B, int C, int H, int W, int axis, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * IntelligentWaveletPoolingModule up to its fusion conv (WPL/iwp.py:124-130; Haar DWT_2D iwp.py:47-113):

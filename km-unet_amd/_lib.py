@@ -41,7 +41,7 @@ SIGNATURES = {
     "kmu_deform_conv2d_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "kmu_deform_conv2d_bwd": (_I, [_P] * 8 + [_I] * 5 + [_P]),
     "kmu_bn_blend_splits": (_I, [_I, _I]),
-    "kmu_bn_blend_fwd": (_I, [_P] * 7 + [_c.c_float, _c.c_float, _I, _I] + [_P] * 3 + [_I] * 3 + [_P]),
+    "kmu_bn_blend_fwd": (_I, [_P] * 7 + [_c.c_float, _c.c_float, _I, _I] + [_P] * 4 + [_I] * 3 + [_P]),
     "kmu_bn_blend_bwd": (_I, [_P] * 7 + [_I, _I] + [_P] * 6 + [_I] * 3 + [_P]),
     "kmu_qkv_gate_fwd": (_I, [_P] * 2 + [_I] * 3 + [_P]),
     "kmu_qkv_gate_bwd": (_I, [_P] * 3 + [_I] * 3 + [_P]),
@@ -56,6 +56,8 @@ SIGNATURES = {
     "kmu_mix3_blocks": (_I, [_I]),
     "kmu_mix3_fwd": (_I, [_P] * 7 + [_I] * 2 + [_P]),
     "kmu_mix3_bwd": (_I, [_P] * 10 + [_I] * 2 + [_P]),
+    "kmu_shift3_fwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
+    "kmu_shift3_bwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
     "kmu_iwp_front_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_iwp_front_bwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_gate_mlp_fwd": (_I, [_P] * 7 + [_I] * 6 + [_P]),

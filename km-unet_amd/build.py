@@ -32,6 +32,7 @@ SOURCES = [
     ("iwp.hip", []),
     ("gauss11.hip", []),
     ("mix3.hip", []),
+    ("shift3.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

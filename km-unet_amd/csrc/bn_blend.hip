@@ -80,9 +80,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ alpha, const float* __restrict__ part,
                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        float momentum, float eps, int relu, int training,
-                                                       float* __restrict__ out, float* __restrict__ stats_out, int B,
-                                                       int C, int HW, int chunk) {
+                                                       float* __restrict__ out, float* __restrict__ stats_out,
+                                                       long long* __restrict__ num_batches_tracked, int B, int C, int HW,
+                                                       int chunk) {
     const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    if (num_batches_tracked && training && gamma && c == 0 && s == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const long N = (long)B * HW;
     float mean = 0.f, rstd = 1.f, g = 1.f, bt = 0.f;
     if (gamma) {
@@ -263,8 +265,8 @@ extern "C" int kmu_bn_blend_splits(int B, int HW) { return split_for(B, HW).S; }
 
 extern "C" int kmu_bn_blend_fwd(const float* t, const float* x, const float* gamma, const float* beta,
                                 const float* alpha, float* running_mean, float* running_var, float momentum, float eps,
-                                int relu, int training, float* out, float* stats, float* ws, int B, int C, int HW,
-                                kmu_stream_t stream) {
+                                int relu, int training, float* out, float* stats, float* ws, long long* num_batches_tracked,
+                                int B, int C, int HW, kmu_stream_t stream) {
     KMU_REQUIRE(t && out, "bn_blend_fwd: null pointer");
     KMU_REQUIRE(!gamma || (beta && running_mean && running_var && stats && ws), "bn_blend_fwd: BatchNorm needs beta, running stats, stats, ws");
     KMU_REQUIRE(!alpha || x, "bn_blend_fwd: a blend needs x");
@@ -277,7 +279,7 @@ extern "C" int kmu_bn_blend_fwd(const float* t, const float* x, const float* gam
         if (rc) return rc;
     }
     hipLaunchKernelGGL(bn_apply_kernel, dim3(C, sp.S), dim3(256), 0, st, t, x, gamma, beta, alpha, ws, running_mean,
-                       running_var, momentum, eps, relu, training, out, stats, B, C, HW, sp.chunk);
+                       running_var, momentum, eps, relu, training, out, stats, num_batches_tracked, B, C, HW, sp.chunk);
     return kmu::launch_status("bn_blend_fwd apply");
 }
 

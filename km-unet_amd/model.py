@@ -114,7 +114,12 @@ class DirectionViM(nn.Module):
         self.attn = DirectionAttention(dim, mode)
 
     def forward(self, x):
-        x = conv1x1(x, self.proj) if self.mode == "channel" else self.proj(x)
+        if self.mode == "channel":
+            x = conv1x1(x, self.proj)
+        elif "conv3tap" not in _TORCH_GLUE and ops.pwconv_supported(3 * x.shape[1], self.proj.out_channels, x.shape[2] * x.shape[3]):
+            x = ops.conv3tap(x, self.proj.weight, self.proj.bias, 0 if self.mode == "height" else 1)
+        else:
+            x = self.proj(x)
         return self.attn(self.vit_mamba(x))
 
 
@@ -215,7 +220,8 @@ class MultiScaleFusion(nn.Module):
         self.fusion = nn.Sequential(nn.Conv2d(co * 3, co, 1), nn.Conv2d(co, co, 3, padding=1), ChannelAttention(co, reduction))
 
     def forward(self, features):
-        return self.fusion(torch.cat([F.silu(group_norm(blk[0](f), blk[1])) for blk, f in zip(self.blocks, features)], dim=1))
+        x = torch.cat([F.silu(group_norm(blk[0](f), blk[1])) for blk, f in zip(self.blocks, features)], dim=1)
+        return self.fusion[2](self.fusion[1](conv1x1(x, self.fusion[0])))
 
 
 class LocalContrastAttention(nn.Module):

@@ -271,7 +271,7 @@ class DySample(nn.Module):
                              .repeat(1, groups, 1).reshape(1, -1, 1, 1))
 
     def forward(self, x):
-        return ops.dysample_lp(x, self.offset(x), self.init_pos)
+        return ops.dysample_lp(x, conv1x1(x, self.offset), self.init_pos)
 
 
 # ------------------------------------------------------------------ DAGEM (K4)
@@ -320,7 +320,8 @@ class DAGEM(nn.Module):
         ue = self.edge_update_func(ef).view(b, h, w, 4, c // 2).permute(0, 4, 1, 2, 3).reshape(-1, 4)
         ue = self.update_edge_reduce_func(ue).view(b, c // 2, h, w)
         deformed = self.deform_conv(x, self.offset_conv(x)) + x
-        return self.final_aggregation_layer(torch.cat((deformed, vert * ue), 1))
+        fa = self.final_aggregation_layer
+        return fa[2](fa[1](conv1x1(torch.cat((deformed, vert * ue), 1), fa[0])))
 
 
 # ------------------------------------------------------------------ WPL/iwp.py (glue)

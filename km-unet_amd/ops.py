@@ -430,6 +430,38 @@ def dwconv3x3_scaled(x, weight, bias, scale):
     return DwConv3x3ScaledFn.apply(x, weight, bias, scale)
 
 
+# ------------------------------------------------------------------------------------------ 3-tap axis convolutions
+class Shift3Fn(torch.autograd.Function):
+    """[B,C,H,W] -> [B,3C,H,W]: the three copies of x shifted by -1, 0, +1 along `axis` (0 = H, 1 = W), zero padded."""
+
+    @staticmethod
+    def forward(ctx, x, axis):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, C, H, W = x.shape
+        out = torch.empty(B, 3 * C, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("shift3_fwd", (B, C, H, W)), lib.kmu_shift3_fwd, _ptr(x), _ptr(out), B, C, H, W, axis, _stream()), "kmu_shift3_fwd")
+        ctx.cfg = (B, C, H, W, axis)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, C, H, W, axis = ctx.cfg
+        g = _f32c(g, "grad")
+        dx = torch.empty(B, C, H, W, device=g.device, dtype=torch.float32)
+        _lib.check(_call(("shift3_bwd", (B, C, H, W)), lib.kmu_shift3_bwd, _ptr(g), _ptr(dx), B, C, H, W, axis, _stream()), "kmu_shift3_bwd")
+        return dx, None
+
+
+def conv3tap(x, weight, bias, axis):
+    """nn.Conv2d with a (3,1) (axis 0) or (1,3) (axis 1) kernel, stride 1, padding 1 on that axis (KM_UNetV3_SH.py:170-172):
+    tap stacking + the pointwise-conv kernels."""
+    co, ci = weight.shape[:2]
+    w2 = weight.reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci)      # W'[co, t*Ci + ci] = W[co, ci, t]
+    return pwconv(Shift3Fn.apply(x, axis), w2, bias)
+
+
 # ------------------------------------------------------------------------------------------ branch fusion
 class Mix3Fn(torch.autograd.Function):
     """out = x + s[b] * (g[b,0] f0 + g[b,1] f1 + g[b,2] f2)  (KM_UNetV3_SH.py:141-146); s = DropPath scale or None."""
@@ -507,7 +539,7 @@ class BnBlendFn(torch.autograd.Function):
     (EfficientViMBlock.forward, efficient_vim_init.py:81-97, with ConvLayer2D's norm/act, vim_utils_init.py:62-89)."""
 
     @staticmethod
-    def forward(ctx, t, x, gamma, beta, a_row, running_mean, running_var, momentum, eps, relu, training):
+    def forward(ctx, t, x, gamma, beta, a_row, running_mean, running_var, momentum, eps, relu, training, nbt=None):
         lib = _lib.load()
         t = _f32c(t, "t")
         x = _f32c(x, "x") if x is not None else None
@@ -523,7 +555,7 @@ class BnBlendFn(torch.autograd.Function):
         ws = torch.empty(C * S * 3, device=dev, dtype=torch.float32)
         _lib.check(_call(("bn_blend_fwd", (B, C, HW)), lib.kmu_bn_blend_fwd, _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row),
                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), int(relu), int(training), _ptr(out),
-                         _ptr(stats), _ptr(ws), B, C, HW, _stream()), "kmu_bn_blend_fwd")
+                         _ptr(stats), _ptr(ws), _ptr(nbt), B, C, HW, _stream()), "kmu_bn_blend_fwd")
         ctx.save_for_backward(t, x, gamma, beta, a_row, stats)
         ctx.cfg = (int(relu), int(training), B, C, HW, S)
         return out
@@ -545,7 +577,7 @@ class BnBlendFn(torch.autograd.Function):
         _lib.check(_call(("bn_blend_bwd", (B, C, HW)), lib.kmu_bn_blend_bwd, _ptr(g), _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta),
                          _ptr(a_row), _ptr(stats), relu, training, _ptr(dt), _ptr(dx), _ptr(dg), _ptr(db), _ptr(da), _ptr(ws),
                          B, C, HW, _stream()), "kmu_bn_blend_bwd")
-        return dt, dx, dg, db, da, None, None, None, None, None, None
+        return dt, dx, dg, db, da, None, None, None, None, None, None, None
 
 
 def bn_blend(t, x=None, bn=None, alpha=None, row=0, relu=False):
@@ -555,9 +587,8 @@ def bn_blend(t, x=None, bn=None, alpha=None, row=0, relu=False):
     if bn is None:
         return BnBlendFn.apply(t, x, None, None, a_row, None, None, 0.0, 0.0, relu, False)
     training = bn.training
-    if training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
-    return BnBlendFn.apply(t, x, bn.weight, bn.bias, a_row, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, training)
+    nbt = bn.num_batches_tracked if training and bn.track_running_stats else None     # incremented by the kernel
+    return BnBlendFn.apply(t, x, bn.weight, bn.bias, a_row, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, training, nbt)
 
 
 # ------------------------------------------------------------------------------------------ sigmoid(q*k)*v

@@ -466,6 +466,26 @@ def test_mix3_vs_torch_cpu(B, C, H, W, drop):
             df1=rel_err(b.grad, f1.grad), df2=rel_err(c.grad, f2.grad), dg=rel_err(gd.grad, g.grad))
 
 
+@pytest.mark.parametrize("B,C,Co,H,W,axis", [(2, 16, 16, 16, 16, 0), (2, 16, 16, 16, 16, 1), (1, 32, 32, 8, 16, 0), (3, 64, 64, 8, 8, 1)])
+def test_conv3tap_vs_torch_cpu(B, C, Co, H, W, axis):
+    """(3,1) / (1,3) convolutions as tap stacking (csrc/shift3.hip) + pointwise conv, against F.conv2d in fp64."""
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H + axis)
+    ks, pad = ((3, 1), (1, 0)) if axis == 0 else ((1, 3), (0, 1))
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
+    x, w, bv = mk(B, C, H, W), mk(Co, C, *ks), mk(Co)
+    gy = torch.randn(B, Co, H, W, generator=gen, dtype=torch.float64)
+    yo = F.conv2d(x, w, bv, padding=pad)
+    yo.backward(gy)
+    dev = lambda t: t.detach().float().to(DEV).requires_grad_(True)
+    xd, wd, bd = dev(x), dev(w), dev(bv)
+    y = ops.conv3tap(xd, wd, bd, axis)
+    y.backward(gy.float().to(DEV))
+    _report("conv3tap %s" % ((B, C, Co, H, W, axis),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad), dw=rel_err(wd.grad, w.grad),
+            db=rel_err(bd.grad, bv.grad))
+
+
 def test_colsum_multi_vs_torch():
     """csrc/colsum.hip: ragged row / column counts, 1..8 arrays per launch, deterministic."""
     ops = _ops()
