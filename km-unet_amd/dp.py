@@ -50,7 +50,17 @@ class FlatGradBucket:
 
     def store(self, grads):
         """Write one gradient per parameter into the bucket (a handful of multi-tensor copy launches)."""
-        torch._foreach_copy_(self.views, list(grads))
+        # the multi-tensor fast path needs matching strides for EVERY pair (one permuted gradient sends all 664 copies
+        # down the per-tensor path: +2.5 ms per step); stragglers are copied on their own
+        fast_v, fast_g = [], []
+        for v, g in zip(self.views, grads):
+            if g.stride() == v.stride() and g.dtype == v.dtype:
+                fast_v.append(v)
+                fast_g.append(g)
+            else:
+                v.copy_(g)
+        if fast_v:
+            torch._foreach_copy_(fast_v, fast_g)
 
     def numel(self):
         return self.flat.numel()
