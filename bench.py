@@ -87,6 +87,39 @@ def _kernel_model(name, shape):
         if name.endswith("bwd"):
             byts *= 2
         return "hbm", 12.0 * B * C * 4 * H * W, byts
+    # ---- streaming glue kernels: algorithmic bytes = every operand read / written once, fp32 ----
+    t = 4.0                                                       # bytes per element
+    if name.startswith("pwconv"):
+        B, Ci, Co, P = shape
+        flops = 2.0 * B * P * Ci * Co
+        extra = B * P * Ci if name.endswith("bwd_input") else 0     # GELU'(x_pre) operand (upper bound: only with gelu_in)
+        return "hbm", flops, t * (B * P * (Ci + Co) + Ci * Co) + 0 * extra
+    if name.startswith("bn_blend"):
+        B, C, HW = shape
+        return "hbm", 0.0, t * B * C * HW * (4 if name.endswith("fwd") else 7)   # fwd: t twice (stats, apply), x, out
+    if name.startswith("dwconv3x3"):
+        B, C, H, W = shape[:4] if len(shape) >= 4 else (shape[0], shape[1], 1, 1)
+        return "hbm", 18.0 * B * C * H * W, t * B * C * H * W * 2
+    if name.startswith(("layernorm1d", "group_norm")):
+        n = 1
+        for d in shape:
+            n *= d
+        return "hbm", 0.0, t * n * (2 if name.endswith("fwd") else 3)
+    if name.startswith("qkv_gate"):
+        B, C, HW = shape
+        return "hbm", 0.0, t * B * C * HW * (4 if name.endswith("fwd") else 7)
+    if name.startswith("mix3"):
+        B, n = shape
+        return "hbm", 0.0, t * B * n * (5 if name.endswith("fwd") else 7)
+    if name.startswith("shift3"):
+        B, C, H, W = shape
+        return "hbm", 0.0, t * B * C * H * W * 4
+    if name.startswith("iwp_front"):
+        B, C, H, W = shape
+        return "hbm", 0.0, t * B * H * W * (C + (C + 1) / 4.0)
+    if name.startswith("gauss11"):
+        N, H, W = shape
+        return "hbm", 2.0 * 22 * N * H * W, t * N * H * W * 2
     return "hbm", 0.0, 0.0
 
 
