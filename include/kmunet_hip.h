@@ -159,6 +159,13 @@ int kmu_deform_conv2d_bwd(const float* x, const float* offset, const float* weig
                           float* d_offset, float* d_weight, float* d_bias, int B, int Cin, int Cout, int H, int W,
                           kmu_stream_t stream);
 
+/* The same operator split for an im2col + GEMM formulation (what km-unet_amd/ops.py uses: the [Cout, Cin*9] contraction
+ * and its two backward GEMMs run on a BLAS): cols [B, Cin*9, H*W] = the bilinear samples; bwd = adjoint of the sampling
+ * (dx must be zero on entry, scatter by atomicAdd; d_offset [B,18,H,W] written in full). */
+int kmu_deform_sample_fwd(const float* x, const float* offset, float* cols, int B, int Cin, int H, int W, kmu_stream_t stream);
+int kmu_deform_sample_bwd(const float* x, const float* offset, const float* dcols, float* dx, float* d_offset, int B, int Cin,
+                          int H, int W, kmu_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Depthwise 3x3 / stride 1 / pad 1 convolution: EfficientViMBlock.dwconv1/dwconv2
  * (vim_block_init/efficient_vim_init.py:74-75 -> ConvLayer2D, vim_utils_init.py:62-89, groups=dim, no bias)

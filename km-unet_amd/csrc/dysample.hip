@@ -93,6 +93,8 @@ __global__ __launch_bounds__(256) void dysample_fwd_kernel(const float* __restri
     }
 }
 
+constexpr int DCH = 8;   // channels whose gathers are in flight together
+
 __global__ __launch_bounds__(256) void dysample_bwd_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ conv_out,
                                                            const float* __restrict__ init_pos,
@@ -114,17 +116,26 @@ __global__ __launch_bounds__(256) void dysample_bwd_kernel(const float* __restri
         const float* dyp = dy + (((size_t)b * C + (size_t)g * cg) * OH + oy) * OW + ox;
         const int o00 = s.y0 * W + s.x0, o01 = s.y0 * W + s.x1, o10 = s.y1 * W + s.x0, o11 = s.y1 * W + s.x1;
         float gpx = 0.f, gpy = 0.f;
-        for (int c = 0; c < cg; ++c) {
-            const float go = dyp[(size_t)c * OH * OW];
-            const float* xc = x + cbase + (size_t)c * hw;
-            float* dxc = dx + cbase + (size_t)c * hw;
-            const float v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
-            atomicAdd(dxc + o00, go * w00);
-            atomicAdd(dxc + o01, go * w01);
-            atomicAdd(dxc + o10, go * w10);
-            atomicAdd(dxc + o11, go * w11);
-            gpx += go * ((v01 - v00) * (1.f - s.fy) + (v11 - v10) * s.fy);
-            gpy += go * ((v10 - v00) * (1.f - s.fx) + (v11 - v01) * s.fx);
+        for (int c0 = 0; c0 < cg; c0 += DCH) {       // gathers issued DCH channels at a time (not one latency chain per channel)
+            float go[DCH], v[DCH][4];
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) {
+                const bool on = c0 + k < cg;
+                const float* xc = x + cbase + (size_t)(c0 + k) * hw;
+                go[k] = on ? dyp[(size_t)(c0 + k) * OH * OW] : 0.f;
+                v[k][0] = on ? xc[o00] : 0.f, v[k][1] = on ? xc[o01] : 0.f, v[k][2] = on ? xc[o10] : 0.f, v[k][3] = on ? xc[o11] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) {
+                if (c0 + k >= cg) continue;
+                float* dxc = dx + cbase + (size_t)(c0 + k) * hw;
+                atomicAdd(dxc + o00, go[k] * w00);
+                atomicAdd(dxc + o01, go[k] * w01);
+                atomicAdd(dxc + o10, go[k] * w10);
+                atomicAdd(dxc + o11, go[k] * w11);
+                gpx += go[k] * ((v[k][1] - v[k][0]) * (1.f - s.fy) + (v[k][3] - v[k][2]) * s.fy);
+                gpy += go[k] * ((v[k][2] - v[k][0]) * (1.f - s.fx) + (v[k][3] - v[k][1]) * s.fx);
+            }
         }
         // d px / d offset = (W/2)*(2/W) = 1 where the coordinate is not clipped (ATen
         // clip_coordinates_set_grad: zero at and beyond the borders); offset = 0.25 * conv_out + init_pos
@@ -169,25 +180,34 @@ __global__ __launch_bounds__(256) void dysample_bwd_tiled_kernel(const float* __
                   l10 = (s.y1 - wy0) * BWIN + (s.x0 - wx0), l11 = (s.y1 - wy0) * BWIN + (s.x1 - wx0);
         const float* dyp = dy + (((size_t)b * C + (size_t)g * cg) * OH + oy) * OW + ox;
         float gpx = 0.f, gpy = 0.f;
-        for (int c = 0; c < cg; ++c) {
-            const float go = dyp[(size_t)c * OH * OW];
-            const float* xc = x + cbase + (size_t)c * hw;
-            const float v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
-            if (inwin) {
-                float* wc = win + c * BWIN * BWIN;
-                atomicAdd(wc + l00, go * w00);
-                atomicAdd(wc + l01, go * w01);
-                atomicAdd(wc + l10, go * w10);
-                atomicAdd(wc + l11, go * w11);
-            } else {
-                float* dxc = dx + cbase + (size_t)c * hw;
-                atomicAdd(dxc + o00, go * w00);
-                atomicAdd(dxc + o01, go * w01);
-                atomicAdd(dxc + o10, go * w10);
-                atomicAdd(dxc + o11, go * w11);
+        for (int c0 = 0; c0 < cg; c0 += DCH) {
+            float go[DCH], v[DCH][4];
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) {
+                const bool on = c0 + k < cg;
+                const float* xc = x + cbase + (size_t)(c0 + k) * hw;
+                go[k] = on ? dyp[(size_t)(c0 + k) * OH * OW] : 0.f;
+                v[k][0] = on ? xc[o00] : 0.f, v[k][1] = on ? xc[o01] : 0.f, v[k][2] = on ? xc[o10] : 0.f, v[k][3] = on ? xc[o11] : 0.f;
             }
-            gpx += go * ((v01 - v00) * (1.f - s.fy) + (v11 - v10) * s.fy);
-            gpy += go * ((v10 - v00) * (1.f - s.fx) + (v11 - v01) * s.fx);
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) {
+                if (c0 + k >= cg) continue;
+                if (inwin) {
+                    float* wc = win + (c0 + k) * BWIN * BWIN;
+                    atomicAdd(wc + l00, go[k] * w00);
+                    atomicAdd(wc + l01, go[k] * w01);
+                    atomicAdd(wc + l10, go[k] * w10);
+                    atomicAdd(wc + l11, go[k] * w11);
+                } else {
+                    float* dxc = dx + cbase + (size_t)(c0 + k) * hw;
+                    atomicAdd(dxc + o00, go[k] * w00);
+                    atomicAdd(dxc + o01, go[k] * w01);
+                    atomicAdd(dxc + o10, go[k] * w10);
+                    atomicAdd(dxc + o11, go[k] * w11);
+                }
+                gpx += go[k] * ((v[k][1] - v[k][0]) * (1.f - s.fy) + (v[k][3] - v[k][2]) * s.fy);
+                gpy += go[k] * ((v[k][2] - v[k][0]) * (1.f - s.fx) + (v[k][3] - v[k][1]) * s.fx);
+            }
         }
         const int h = oy >> 1, i = oy & 1, w = ox >> 1, j = ox & 1;
         const int chx = g * 4 + i * 2 + j, chy = 16 + chx;

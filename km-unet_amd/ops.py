@@ -333,8 +333,50 @@ class DeformConv2dFn(torch.autograd.Function):
         return dx, doff, dw, (db if ctx.has_bias else None)
 
 
-def deform_conv2d(x, offset, weight, bias=None):
+def deform_conv2d_fused(x, offset, weight, bias=None):
+    """Single-launch VALU variant (kmu_deform_conv2d_fwd/bwd): self-contained, but latency-bound at KM-UNet's size."""
     return DeformConv2dFn.apply(x, offset, weight, bias)
+
+
+class DeformSampleFn(torch.autograd.Function):
+    """cols [B, Cin*9, H*W] = bilinear samples of x at the 9 deformed taps of every output pixel (the im2col half of
+    torchvision.ops.DeformConv2d, DAGEM_md.py:98-101); backward scatters d cols into dx and yields d offset."""
+
+    @staticmethod
+    def forward(ctx, x, offset):
+        lib = _lib.load()
+        x, offset = _f32c(x, "x"), _f32c(offset, "offset")
+        B, Cin, H, W = x.shape
+        cols = torch.empty(B, Cin * 9, H * W, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("deform_sample_fwd", (B, Cin, H, W)), lib.kmu_deform_sample_fwd, _ptr(x), _ptr(offset), _ptr(cols), B, Cin, H, W,
+                         _stream()), "kmu_deform_sample_fwd")
+        ctx.save_for_backward(x, offset)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        lib = _lib.load()
+        x, offset = ctx.saved_tensors
+        dcols = _f32c(dcols, "dcols")
+        B, Cin, H, W = x.shape
+        dx, doff = torch.zeros_like(x), torch.empty_like(offset)
+        _lib.check(_call(("deform_sample_bwd", (B, Cin, H, W)), lib.kmu_deform_sample_bwd, _ptr(x), _ptr(offset), _ptr(dcols), _ptr(dx),
+                         _ptr(doff), B, Cin, H, W, _stream()), "kmu_deform_sample_bwd")
+        return dx, doff
+
+
+def deform_conv2d(x, offset, weight, bias=None):
+    """Deformable 3x3 conv = sampling kernel (columns) + a [Cout, Cin*9] GEMM (rocBLAS through torch.matmul; its two
+    backward GEMMs replace 4.7 M float atomics of the fused kernel's weight gradient)."""
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (Cin, 3, 3) or tuple(offset.shape) != (B, 18, H, W):
+        raise RuntimeError("DeformConv2d: only 3x3/stride1/pad1/one offset group is built (weight %s, offset %s)"
+                           % (tuple(weight.shape), tuple(offset.shape)))
+    y = torch.matmul(weight.reshape(Cout, Cin * 9), DeformSampleFn.apply(x, offset))
+    if bias is not None:
+        y = y + bias.view(1, -1, 1)
+    return y.view(B, Cout, H, W)
 
 
 # ------------------------------------------------------------------------------------------ depthwise 3x3

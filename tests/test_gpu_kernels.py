@@ -201,8 +201,9 @@ def test_k3_indices_bit_exact_large(B, H, W, std):
 
 
 # ------------------------------------------------------------------------------------------ K4
+@pytest.mark.parametrize("variant", ["sample_gemm", "fused"])
 @pytest.mark.parametrize("B,C,Co,H,W,std", [(2, 64, 64, 16, 16, 0.5), (1, 8, 12, 7, 9, 2.0), (2, 16, 16, 8, 8, 5.0)])
-def test_k4_vs_oracle(B, C, Co, H, W, std):
+def test_k4_vs_oracle(B, C, Co, H, W, std, variant):
     from oracle import deform as odf
     ops = _ops()
     gen = torch.Generator().manual_seed(C + H)
@@ -214,9 +215,9 @@ def test_k4_vs_oracle(B, C, Co, H, W, std):
     yo = odf.deform_conv2d(x, off, wt, bs)
     yo.backward(gy)
     d = [t.detach().to(DEV).requires_grad_(True) for t in (x, off, wt, bs)]
-    y = ops.deform_conv2d(*d)
+    y = (ops.deform_conv2d if variant == "sample_gemm" else ops.deform_conv2d_fused)(*d)
     y.backward(gy.to(DEV))
-    _report("k4 %s" % ((B, C, Co, H, W),), y=rel_err(y, yo), dx=rel_err(d[0].grad, x.grad), doff=rel_err(d[1].grad, off.grad),
+    _report("k4 %s %s" % (variant, (B, C, Co, H, W)), y=rel_err(y, yo), dx=rel_err(d[0].grad, x.grad), doff=rel_err(d[1].grad, off.grad),
             dw=rel_err(d[2].grad, wt.grad), db=rel_err(d[3].grad, bs.grad))
 
 
