@@ -51,24 +51,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     const int b = blockIdx.x / bpp, p0 = (blockIdx.x % bpp) * 256 + wave * 64;
     const int n0 = blockIdx.y * 16 * NT;
 
-    // x loads do not depend on the LDS weights: the first two batches (2 chunks = 32 channels each, 8 float4 per lane) are
-    // issued before the staging so both global round trips overlap; afterwards the two register buffers ping-pong, the
-    // loads of one always in flight behind the MFMAs of the other.
-    const int nchunk = K / 16;
-    const bool live = p0 < P;
-    const float* xb = x + (size_t)b * K * P + (live ? p0 : 0) + 4 * ((m >> 2) + 4 * (m & 3));
-    floatx4 xa[2][4], xc[2][4];
-    auto load2 = [&](floatx4 (&buf)[2][4], int c) {          // chunks c, c+1 (zeros past the end)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                buf[j][s] = (live && c + j < nchunk) ? *reinterpret_cast<const floatx4*>(xb + (size_t)(16 * (c + j) + 4 * q + s) * P)
-                                                     : floatx4{0.f, 0.f, 0.f, 0.f};
-    };
-    load2(xa, 0);
-    load2(xc, 2);
-
     // stage W[n0 .. n0+16NT) x [0, K) -> wl[k][n]
     if (w_sk == 1) {
         for (int e = tid; e < 16 * NT * K; e += 256) {
@@ -82,42 +64,43 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    if (!live) return;
+    if (p0 >= P) return;
 
+    const float* xb = x + (size_t)b * K * P + p0 + 4 * ((m >> 2) + 4 * (m & 3));
     floatx4 acc[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[nt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    auto mac2 = [&](floatx4 (&buf)[2][4], int c) {           // chunks c, c+1
+    floatx4 xv[4], xn[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (c + j >= nchunk) break;
-            if (act_in) {
+    for (int s = 0; s < 4; ++s) xv[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(4 * q + s) * P);
+    const int nchunk = K / 16;
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) buf[j][s][t] = gelu_f(buf[j][s][t]);
-            }
-            const float* wrow = wl + (16 * (c + j) + 4 * q) * S + m;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float bf[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bf[nt] = wrow[s * S + 16 * nt];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[j][s][t], bf[nt], acc[nt][t], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) xn[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(16 * (c + 1) + 4 * q + s) * P);
         }
-    };
-    for (int c0 = 0; c0 < nchunk; c0 += 4) {
-        mac2(xa, c0);
-        if (c0 + 4 < nchunk) load2(xa, c0 + 4);
-        if (c0 + 2 < nchunk) mac2(xc, c0 + 2);
-        if (c0 + 6 < nchunk) load2(xc, c0 + 6);
+        if (act_in) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xv[s][t] = gelu_f(xv[s][t]);
+        }
+        const float* wrow = wl + (16 * c + 4 * q) * S + m;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = wrow[s * S + 16 * nt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s][t], bf[nt], acc[nt][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xv[s] = xn[s];
     }
 
     // epilogue: lane owns channel n0 + 16nt + m, pixels p0 + 16i + 4q + t
