@@ -25,7 +25,6 @@ import time
 import warnings
 
 os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")       # km-unet_amd/__init__.py: numerics policy
-os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")   # idem
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")    # km-unet_amd/__init__.py: hipGraph replay policy
 
 import torch  # noqa: E402

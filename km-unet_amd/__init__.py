@@ -4,44 +4,21 @@ The directory name carries a hyphen; import it as ``km_unet_amd`` (root-level km
 registers this directory under that module name).
 """
 import os as _os
-import sys as _sys
-import warnings as _warnings
 
-# ---- process-wide numerics / runtime policy -------------------------------------------------------------------------
-# MIOpen (PyTorch-ROCm's conv backend for the glue convolutions) parses its MIOPEN_DEBUG_* variables when libMIOpen.so is
-# LOADED, i.e. at `import torch` (measured: tools/env_order_probe.py -- set after the import they are ignored).  They
-# therefore only take effect if this package (or the entry script) is imported before torch; bench.py,
-# __graft_entry__.py and tests/conftest.py set them first thing.  Otherwise a warning says what is lost.
-#  * MIOPEN_DEBUG_CONV_WINOGRAD=0: the Winograd solvers (miopenSp3AsmConv f2x3/f3x2) are picked or not depending on a
-#    timing-based Find step and move whole-model fp32 gradients by 1.5e-4 .. 1.4e-3 relative (5e-6 without them);
-#  * MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC=0: with the asm implicit-GEMM backward-data solver
-#    (igemm_bwd_gtcx35_nhwc_fp32) in the mix, 504 of 649 parameter gradients of the eval-mode model move by
-#    2e-4 .. 6e-3 relative and dL/dx by 1.1e-3 (tools/smoke_bisect*.sh; 5e-5 without it, forward unaffected).
-#    Excluding just that solver costs nothing measurable (20.96 vs 20.70 ms/step); excluding the whole implicit-GEMM
-#    family would send MIOpen to an 18 ms naive weight-gradient kernel.
-# Both are above / at the 1e-3 parity budget against the reference's CPU fp32 path, hence excluded.
-MIOPEN_POLICY = {"MIOPEN_DEBUG_CONV_WINOGRAD": "0", "MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC": "0"}
-# hipGraph policy: the HIP runtime's AQL packet capture for graphs (default on in ROCm 7) replays the multi-thousand-node
-# train-step graph wrongly once the host has synchronised the stream between two replays -- reductions inside the
-# captured loss return garbage from then on (measured on MI355X, tools/repro_graph_replay_sync.py: 0.4332 -> 216.4;
-# correct with the capture path off, every other runtime knob made no difference).  Read at HIP runtime
-# initialisation (the first HIP call of the process), so setting it here is early enough unless HIP is already up.
-HIP_POLICY = {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}
-
-
-def _apply_policy():
-    torch_loaded = "torch" in _sys.modules
-    late = [k for k in MIOPEN_POLICY if k not in _os.environ] if torch_loaded else []
-    for k, v in {**MIOPEN_POLICY, **HIP_POLICY}.items():
-        _os.environ.setdefault(k, v)
-    if late:
-        _warnings.warn("km_unet_amd was imported after torch: MIOpen has already read its environment, so %s cannot be "
-                       "applied any more and fp32 gradient parity with the reference degrades from ~5e-5 to ~1e-3. Import "
-                       "km_unet_amd before torch, or export these variables (=0) in the environment." % ", ".join(late),
-                       RuntimeWarning, stacklevel=3)
-
-
-_apply_policy()
+# ---- process-wide numerics / runtime policy (only defaults: anything already in the environment wins) ---------------
+# MIOpen reads its MIOPEN_DEBUG_* variables when it first needs them and the HIP runtime reads its flags when it
+# initialises (first HIP call), so setting them at package import is early enough even after `import torch`
+# (measured: tools/env_order_probe.py) -- as long as no convolution has run / no HIP call has been made yet.
+#  * MIOPEN_DEBUG_CONV_WINOGRAD=0 -- precaution for fp32 parity: fp32 Winograd transforms carry a larger rounding error
+#    than direct / implicit-GEMM convolution and whether MIOpen picks them depends on a timing-based search, i.e. on the
+#    box.  None of the glue convolutions in profiles/ ran on a Winograd kernel, so nothing is lost.
+#  * DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 -- the HIP runtime's AQL packet capture for graphs (default on in ROCm 7) replays
+#    the multi-thousand-node train-step graph wrongly once the host has synchronised the stream between two replays:
+#    reductions inside the captured loss return garbage from then on (measured on MI355X,
+#    tools/repro_graph_replay_sync.py: 0.4332 -> 216.4; correct with the capture path off, six other runtime knobs
+#    made no difference, profiles/r01c_graph_replay_runtime_knobs.log).  No cost in step time.
+_os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 from . import _lib, ops  # noqa: E402,F401
 from .model import KM_UNetV3  # noqa: E402,F401

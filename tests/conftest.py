@@ -3,7 +3,6 @@ import sys
 import warnings
 
 os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")   # same numerics policy as km-unet_amd/__init__.py
-os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")   # idem
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # same hipGraph policy as km-unet_amd/__init__.py
 
 import numpy as np
