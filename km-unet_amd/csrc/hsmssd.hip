@@ -27,6 +27,11 @@ using kmu::floatx4;
 namespace {
 
 constexpr int NS = 64;  // state_dim
+#ifndef KMU_TY16_MAXC
+#define KMU_TY16_MAXC 16   // channel counts up to this use 16x16 token tiles in pass 1 / pass 2 / pass A, larger ones 8x16:
+                           // measured on MI355X (B=8): C=32 @64x64 pass1 56->38 us, passA 50->33, pass2 35->25 with 8x16 tiles
+                           // (35 KB LDS => 4 workgroups per CU instead of 2); C=16 @128x128 loses (twice the tiles to combine)
+#endif
 
 __host__ __device__ constexpr int pad_mod32(int n, int want) { return n + ((want - (n % 32)) + 32) % 32; }
 
@@ -45,7 +50,7 @@ struct Geo {
 
 template <int C>
 struct TileFor {
-    static constexpr int TY = (C <= 32) ? 16 : 8;
+    static constexpr int TY = (C <= KMU_TY16_MAXC) ? 16 : 8;
 };
 
 // ---- stage the halo tile of x[b] : xs[c][pos], zero outside the image --------------------------
@@ -609,7 +614,7 @@ size_t lds_pass2() {
     return ((size_t)C * G::XS + 16 * G::XS + 16 * G::CMS) * sizeof(float);
 }
 inline int tiles_for(int C, int Hs, int* tilesX) {
-    const int TY = (C <= 32) ? 16 : 8;
+    const int TY = (C <= KMU_TY16_MAXC) ? 16 : 8;
     *tilesX = kmu::cdiv(Hs, 16);
     return *tilesX * kmu::cdiv(Hs, TY);
 }
