@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void hsm_fwd_pass1(const float* __restrict__ x
 
     float* ms_out = part_ms + ((size_t)b * T + tile) * 2 * NS;
 
+    // The 8 chunks produce disjoint state columns n (their partials never meet), so at the coarse levels, where the tile
+    // count alone cannot fill 256 CUs, gridDim.z = 2 or 4 workgroups share a tile's chunks -- no extra reduction.
+    const int cpz = 8 / gridDim.z, ch0 = blockIdx.z * cpz;
 #pragma unroll 1
-    for (int ch = 0; ch < 8; ++ch) {  // 8 chunks of 8 states: P rows {B: n0..n0+7, dt: 128+n0..}
+    for (int ch = ch0; ch < ch0 + cpz; ++ch) {  // chunks of 8 states: P rows {B: n0..n0+7, dt: 128+n0..}
         const int n0 = ch * 8;
         __syncthreads();  // xs staged (first trip) / previous Ps + wBs consumers done
         proj_chunk<C, TY>(Ps, xs, w_bcdt, n0, 2 * NS + n0, wave, li, lq);
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void hsm_fwd_pass1(const float* __restrict__ x
         if (ch & 1) {
             __syncthreads();  // wBs for 16 states complete
             // acc[n][c] += sum_tok wB[n][tok] * x[c][tok];  this wave covers token quads [16*wave, 16*wave+16)
-            const int a = ch >> 1;
+            const int a = (ch - ch0) >> 1;
 #pragma unroll 4
             for (int kq = 0; kq < G::NSTRIP / 4; ++kq) {
                 const int sq = wave * (G::NSTRIP / 4) + kq;   // strip index = token quad
@@ -224,8 +227,8 @@ __global__ __launch_bounds__(256) void hsm_fwd_pass1(const float* __restrict__ x
             for (int r = 0; r < 4; ++r)
                 red[(wave * NS + a * 16 + lq * 4 + r) * C + c * 16 + li] = acc[a][c][r];  // D[n][c]: col c=li
     __syncthreads();
-    float* acc_out = part_acc + ((size_t)b * T + tile) * NS * C;
-    for (int e = tid; e < NS * C; e += 256)
+    float* acc_out = part_acc + ((size_t)b * T + tile) * NS * C + (size_t)ch0 * 8 * C;   // this workgroup's rows n
+    for (int e = tid; e < cpz * 8 * C; e += 256)
         acc_out[e] = red[e] + red[NS * C + e] + red[2 * NS * C + e] + red[3 * NS * C + e];
 }
 
@@ -613,6 +616,9 @@ size_t lds_pass2() {
     using G = Geo<TileFor<C>::TY>;
     return ((size_t)C * G::XS + 16 * G::XS + 16 * G::CMS) * sizeof(float);
 }
+// workgroups per tile in pass 1 / pass A (their chunks own disjoint state columns): enough to give every CU work
+inline int chunk_split(int tile_workgroups) { return tile_workgroups < 128 ? 4 : (tile_workgroups < 512 ? 2 : 1); }
+
 inline int tiles_for(int C, int Hs, int* tilesX) {
     const int TY = (C <= KMU_TY16_MAXC) ? 16 : 8;
     *tilesX = kmu::cdiv(Hs, 16);
@@ -631,7 +637,8 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
     int rc = 0;
     if (stages & 1) {
         KMU_MAX_LDS(hsm_fwd_pass1<C>, l1);
-        hipLaunchKernelGGL(hsm_fwd_pass1<C>, dim3(T, B), dim3(256), l1, st, x, w_bcdt, w_dw, part_ms, part_acc, Hs, tilesX);
+        hipLaunchKernelGGL(hsm_fwd_pass1<C>, dim3(T, B, chunk_split(T * B)), dim3(256), l1, st, x, w_bcdt, w_dw, part_ms, part_acc, Hs,
+                           tilesX);
         rc = kmu::launch_status("hsmssd_fwd pass1");
         if (rc) return rc;
     }
