@@ -545,3 +545,35 @@ def test_error_paths():
     with pytest.raises(RuntimeError):
         km_unet_amd.ops.kan_conv2d(torch.randn(1, 4, 4, 4), torch.zeros(36, 12), torch.zeros(4, 36), torch.zeros(4, 36, 8),
                                    torch.zeros(4, 36))          # CPU tensor: no fallback
+
+
+def test_error_paths_glue_kernels():
+    """Every glue entry point refuses shapes it is not built for (message, no launch) instead of computing garbage."""
+    import km_unet_amd
+    from km_unet_amd import _lib, ops
+    lib = _lib.load()
+    d = lambda *s: torch.randn(*s, device=DEV)
+    err = lambda: lib.kmu_last_error().decode()
+    bad = [
+        (lambda: ops.pwconv(d(1, 20, 8, 8), d(16, 20, 1, 1)), "multiples of 16"),            # Ci % 16
+        (lambda: ops.pwconv(d(1, 16, 6, 6), d(16, 16, 1, 1)), "multiple of 64"),             # H*W % 64
+        (lambda: ops.pwconv(d(1, 512, 8, 8), d(16, 512, 1, 1)), "LDS weight tile"),          # contraction too long
+        (lambda: ops.gate_mlp(d(64, 256), d(256, 256), None, d(256, 256), None), "LDS"),     # B*(I+2H+O) floats > 144 KB
+        (lambda: ops.iwp_front(d(1, 4, 5, 8), d(1, 12, 1, 1), d(1)), "even"),
+        (lambda: ops.mix3(d(1, 3, 1, 1), d(1, 3, 1, 1), d(1, 3, 1, 1), d(1, 3, 1, 1), d(1, 3)), "multiple of 4"),
+        (lambda: ops.gauss11(d(1, 1, 8, 8), d(11)), "smaller than"),
+        (lambda: ops.Shift3Fn.apply(d(1, 2, 4, 4), 2), "axis"),
+        (lambda: ops.deform_conv2d(d(1, 4, 4, 4), d(1, 18, 4, 4), d(4, 4, 5, 5)), "3x3"),
+    ]
+    for fn, needle in bad:
+        with pytest.raises(RuntimeError) as ei:
+            fn()
+        assert needle in str(ei.value), (needle, str(ei.value))
+    assert not ops.pwconv_supported(20, 16, 64) and not ops.pwconv_supported(16, 16, 36) and ops.pwconv_supported(48, 16, 128)
+    assert lib.kmu_colsum_multi(0, None, None, None, None, None) != 0 and "arrays" in err()
+    assert lib.kmu_pwconv_bwd_weight_ws_bytes(1, 20, 16, 64) == 0
+    for cpu_call in (lambda: ops.pwconv(torch.randn(1, 16, 8, 8), torch.randn(16, 16, 1, 1)),
+                     lambda: ops.iwp_front(torch.randn(1, 4, 4, 4), torch.randn(1, 12, 1, 1), None),
+                     lambda: ops.gate_mlp(torch.randn(2, 4), torch.randn(2, 4), None, torch.randn(4, 2), None)):
+        with pytest.raises(RuntimeError):        # CPU tensors: the product has no CPU fallback
+            cpu_call()
