@@ -551,6 +551,8 @@ class Gauss11Fn(torch.autograd.Function):
         lib = _lib.load()
         x = _f32c(x, "x")
         H, W = x.shape[-2:]
+        if H < 11 or W < 11:
+            raise RuntimeError("gauss11: %dx%d is smaller than the 11x11 window" % (H, W))
         N = x.numel() // (H * W)
         out = torch.empty(*x.shape[:-2], H - 10, W - 10, device=x.device, dtype=torch.float32)
         _lib.check(_call(("gauss11_filter", (N, H, W)), lib.kmu_gauss11_filter, _ptr(x), _ptr(taps), _ptr(out), N, H, W, 0, _stream()),
