@@ -276,6 +276,9 @@ struct WgradPlan {
     size_t slab_floats, bslab_floats;
 };
 
+#ifndef KMU_PW_GMAX
+#define KMU_PW_GMAX 256   // workgroups (= slabs) per slice pair; measured at B=8, 128x128: 512 -> 25 us, 256 -> 20 us, 128 -> 22 us per wgrad
+#endif
 inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
     WgradPlan pl;
     pl.MT = pick_tiles(Co / 16);
@@ -283,7 +286,7 @@ inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
     pl.nsp = (Co / (16 * pl.MT)) * (Ci / (16 * pl.NT));
     pl.nchunks = B * (P / 32);
     int G = pl.nchunks / 8;                        // >= 2 chunks per wave
-    G = G < 1 ? 1 : (G > 512 ? 512 : G);
+    G = G < 1 ? 1 : (G > KMU_PW_GMAX ? KMU_PW_GMAX : G);
     while (G > 32 && (size_t)G * pl.MT * pl.NT * 1024 * pl.nsp > ((size_t)4 << 20)) G /= 2;   // keep the slabs <= 4 MB
     pl.G = G;
     pl.nw = 4 * G;
