@@ -566,10 +566,13 @@ int launch_bwd_input(const float* x, const float* dy, const float* knots, const 
     return kmu::launch_status("kan_conv2d_bwd_input");
 }
 
+#ifndef KMU_KAN_WSLABS
+#define KMU_KAN_WSLABS 512   // weight-gradient workgroups (= 83 KB slabs) per layer; measured at site 1 (B=8): 256 -> 281 us, 512 -> 238 us, 1024 -> 323 us
+#endif
 int bwd_weight_splits(int B, int Cin, int Cout, int H, int W) {
     const int CT = kmu::cdiv(Cin, 16), OT = kmu::cdiv(Cout, 16);
     const int ntiles = B * kmu::cdiv(H, BwdWGeom::TH) * kmu::cdiv(W, BwdWGeom::TW);
-    int S = 512 / (CT * OT);
+    int S = KMU_KAN_WSLABS / (CT * OT);
     if (S < 1) S = 1;
     if (S > ntiles) S = ntiles;
     return S;
