@@ -101,6 +101,27 @@ class KANLinear(nn.Module):
             self.spline_weight.copy_(coef.t().reshape(self.in_features, self.out_features, -1).permute(1, 0, 2))
 
 
+    @property
+    def scaled_spline_weight(self):
+        """KANlayers.py:644-650 (enable_standalone_scale_spline is always on here)."""
+        return self.spline_weight * self.spline_scaler.unsqueeze(-1)
+
+    def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
+        """KANlayers.py:713-731: with a[o,i] = mean_k |spline_weight[o,i,k]|, returns
+        regularize_activation * sum(a) + regularize_entropy * entropy(a / sum(a)).  Parameter-only, plain tensor ops."""
+        a = self.spline_weight.abs().mean(dim=-1)
+        total = a.sum()
+        p = a / total
+        return regularize_activation * total - regularize_entropy * torch.sum(p * torch.log(p))
+
+    def update_grid(self, x, margin=0.01):
+        """KANlayers.py:662-711 re-fits a separate, data-adaptive knot vector per input feature.  The HIP kernels evaluate
+        the basis once per input element against ONE shared knot vector (that is where the 9x saving over the unfolded
+        evaluation comes from), and KM-UNet never calls this method, so it is not provided."""
+        raise NotImplementedError("KANLinear.update_grid: per-feature adaptive knot vectors are not supported by the HIP "
+                                  "kernels (one shared knot vector per layer); KM-UNet does not use it")
+
+
 def _bspline_collocation(x, knots, order):
     x = x.unsqueeze(-1)
     b = ((x >= knots[:-1]) & (x < knots[1:])).to(x.dtype)

@@ -60,6 +60,14 @@ def kan_conv2d(x, grid, base_weight, spline_weight, spline_scaler, kernel_size=3
     return y.reshape(b, -1, y.shape[1]).transpose(1, 2).reshape(b, -1, oh, ow)
 
 
+def regularization_loss(spline_weight, regularize_activation=1.0, regularize_entropy=1.0):
+    """KANlayers.py:713-731 (parameter-only surrogate of the KAN paper's L1 + entropy regulariser)."""
+    a = spline_weight.abs().mean(dim=-1)
+    total = a.sum()
+    p = a / total
+    return regularize_activation * total - regularize_entropy * (p * p.log()).sum()
+
+
 class KANLinear(nn.Module):
     """State-dict compatible with reference KANLinear (KANlayers.py:505-575)."""
 
@@ -80,6 +88,10 @@ class KANLinear(nn.Module):
 
     def forward(self, x):
         return kan_linear(x, self.grid, self.base_weight, self.spline_weight, self.spline_scaler)
+
+    def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
+        """KANlayers.py:713-731: a = mean_k |spline_weight| per (out, in) edge; loss = ra * sum(a) + re * H(a / sum(a))."""
+        return regularization_loss(self.spline_weight, regularize_activation, regularize_entropy)
 
 
 class KANConv2d(nn.Module):

@@ -8,6 +8,7 @@ reference's outputs / gradients -- never reference source.
 
 What each fixture pins (reference file:line):
   k1_*.npz     convKAN/KANConv2Dlayers.py:15-37 + KANlayers.py:577-660
+  kan_reg.npz  KANlayers.py:713-731 (regularization_loss)
   k2_*.npz     vim_block_init/efficient_vim_init.py:33-61 (+ LayerNorm1D vim_utils_init.py:50-59)
   evim_*.npz   vim_block_init/efficient_vim_init.py:81-97 (EfficientViMBlock, train + eval BN)
   k3_*.npz     DySample_md.py:49-68 (+ integer gather indices from the oracle's
@@ -81,6 +82,13 @@ def gen_k1(ref):
         save(name, x=x, gy=gy, grid=k.grid, base_weight=k.base_weight, spline_weight=k.spline_weight,
              spline_scaler=k.spline_scaler, y=y, dx=x.grad, d_base_weight=k.base_weight.grad,
              d_spline_weight=k.spline_weight.grad, d_spline_scaler=k.spline_scaler.grad)
+
+
+def gen_kan_reg(ref):
+    """KANLinear.regularization_loss (KANlayers.py:713-731) of the reference for explicit spline weights."""
+    m = ref.kanconv.KANConv2d(4, 8, 3, padding=1).kanlayer
+    set_params(m, 77, lambda k, p: 0.2)
+    save("kan_reg", spline_weight=m.spline_weight, r11=m.regularization_loss(1.0, 1.0), r03_2=m.regularization_loss(0.3, 2.0))
 
 
 # ---------------------------------------------------------------- K2
@@ -199,6 +207,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     ref = ref_loader.load()
     gen_k1(ref)
+    gen_kan_reg(ref)
     gen_k2(ref)
     gen_evim(ref)
     gen_k3(ref)

@@ -99,3 +99,24 @@ def test_dropin_import_paths():
         "print('ok')\n") % os.path.join(ROOT, "km-unet_amd", "dropin")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_kanlinear_api_completeness():
+    """KANLinear.regularization_loss / scaled_spline_weight (KANlayers.py:644-650,713-731) are parameter-only and run
+    anywhere; update_grid is refused with a reason (per-feature knot vectors)."""
+    import pytest
+    import torch
+    import km_unet_amd
+    from oracle import kan as okan
+    torch.manual_seed(3)
+    m = km_unet_amd.KANLinear(36, 8)
+    o = okan.KANLinear(36, 8)
+    o.load_state_dict(m.state_dict())
+    for ra, re in ((1.0, 1.0), (0.3, 2.0)):
+        assert torch.allclose(m.regularization_loss(ra, re), o.regularization_loss(ra, re), rtol=1e-6, atol=0)
+    assert m.scaled_spline_weight.shape == (8, 36, 8)
+    assert torch.equal(m.scaled_spline_weight, m.spline_weight * m.spline_scaler[..., None])
+    m.regularization_loss().backward()
+    assert m.spline_weight.grad is not None and m.base_weight.grad is None
+    with pytest.raises(NotImplementedError):
+        m.update_grid(torch.randn(4, 36))

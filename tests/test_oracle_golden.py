@@ -124,3 +124,18 @@ def test_state_dict_manifest(fname, variant, nc):
     assert sorted(map(tuple, got)) == sorted(map(tuple, want))
     if variant == "SH":
         assert len(got) == 920
+
+
+def test_kan_regularization_loss_golden():
+    """oracle.kan.regularization_loss and the product's KANLinear.regularization_loss against the reference's values."""
+    import km_unet_amd
+    from oracle import kan as okan
+    g = load_golden("kan_reg")
+    sw = g["spline_weight"]
+    assert torch.allclose(okan.regularization_loss(sw, 1.0, 1.0), g["r11"], rtol=1e-6)
+    assert torch.allclose(okan.regularization_loss(sw, 0.3, 2.0), g["r03_2"], rtol=1e-6)
+    m = km_unet_amd.KANLinear(sw.shape[1], sw.shape[0])
+    with torch.no_grad():
+        m.spline_weight.copy_(sw)
+    assert torch.allclose(m.regularization_loss(1.0, 1.0), g["r11"], rtol=1e-6)
+    assert torch.allclose(m.regularization_loss(0.3, 2.0), g["r03_2"], rtol=1e-6)
