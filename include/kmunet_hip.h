@@ -271,6 +271,28 @@ int kmu_shift3_fwd(const float* x, float* out, int B, int C, int H, int W, int a
 int kmu_shift3_bwd(const float* gout, float* dx, int B, int C, int H, int W, int axis, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * HybridLoss of the training loop (train_shanghai.py:298-325) on N = B*C planes [H,W] (H, W >= 12), fused around
+ * kmu_gauss11_filter.  stats: 8 floats on the device {sum (P-T)^2, sum (P-T)^2 e^{2T}, min P, max P, min T, max T,
+ * sum SSIM map, loss}; part: 6 * kmu_hybrid_loss_blocks(N,H,W) floats of scratch.
+ * Forward, in order:  stats (fills stats[0..5])  ->  stack [5][N][H+10][W+10] = {p, t, p^2, t^2, pt} of the min-max
+ * normalised, reflect-padded inputs  ->  kmu_gauss11_filter(stack -> filt [5][N][H][W], adjoint 0)  ->  combine
+ * (SSIM map over the border-cropped interior, stats[6], loss -> stats[7]).
+ * Backward: grad_maps (gmaps [3][N][H][W] = d loss / d {mu_p, E_pp, E_pt}; gout = upstream scalar on the device) ->
+ * kmu_gauss11_filter(gmaps -> q [3][N][H+10][W+10], adjoint 1) -> grad_input (d loss / d pred, incl. the MSE terms;
+ * the extrema are constants, the target gets no gradient).
+ * ------------------------------------------------------------------------------------ */
+int kmu_hybrid_loss_blocks(int N, int H, int W);
+int kmu_hybrid_loss_stats(const float* pred, const float* target, float* part, float* stats, int N, int H, int W,
+                          kmu_stream_t stream);
+int kmu_hybrid_loss_stack(const float* pred, const float* target, const float* stats, float* stack, int N, int H, int W,
+                          kmu_stream_t stream);
+int kmu_hybrid_loss_combine(const float* filt, float* part, float* stats, int N, int H, int W, float alpha, kmu_stream_t stream);
+int kmu_hybrid_loss_grad_maps(const float* filt, const float* gout, float* gmaps, int N, int H, int W, float alpha,
+                              kmu_stream_t stream);
+int kmu_hybrid_loss_grad_input(const float* pred, const float* target, const float* stats, const float* q, const float* gout,
+                               float* dpred, int N, int H, int W, float alpha, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * IntelligentWaveletPoolingModule up to its fusion conv (WPL/iwp.py:124-130; Haar DWT_2D iwp.py:47-113):
  * x [B,C,H,W] (H, W even) -> out [B,C+1,H/2,W/2] = cat[LL, mean over the 3C channels of cat[LH,HL,HH]].  The
  * Softmax2d attention over one channel (iwp.py:127) is identically 1, its conv receives an exactly-zero gradient.

@@ -60,6 +60,12 @@ SIGNATURES = {
     "kmu_mix3_bwd": (_I, [_P] * 10 + [_I] * 2 + [_P]),
     "kmu_shift3_fwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
     "kmu_shift3_bwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
+    "kmu_hybrid_loss_blocks": (_I, [_I] * 3),
+    "kmu_hybrid_loss_stats": (_I, [_P] * 4 + [_I] * 3 + [_P]),
+    "kmu_hybrid_loss_stack": (_I, [_P] * 4 + [_I] * 3 + [_P]),
+    "kmu_hybrid_loss_combine": (_I, [_P] * 3 + [_I] * 3 + [_c.c_float, _P]),
+    "kmu_hybrid_loss_grad_maps": (_I, [_P] * 3 + [_I] * 3 + [_c.c_float, _P]),
+    "kmu_hybrid_loss_grad_input": (_I, [_P] * 6 + [_I] * 3 + [_c.c_float, _P]),
     "kmu_iwp_front_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_iwp_front_bwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_gate_mlp_fwd": (_I, [_P] * 7 + [_I] * 6 + [_P]),

@@ -33,6 +33,7 @@ SOURCES = [
     ("gauss11.hip", []),
     ("mix3.hip", []),
     ("shift3.hip", []),
+    ("hybrid_loss.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,250 @@
+// HybridLoss of the reference training loop (train_shanghai.py:298-325) around the separable window filter of
+// csrc/gauss11.hip:
+//     loss = a (0.55 mse + 0.45 mean((P-T)^2 exp(2T))) + (1-a) (1 - SSIM(Pn, Tn)),   Pn = (P - min P)/(max P - min P + 1e-8)
+// SSIM = torchmetrics' StructuralSimilarityIndexMeasure(data_range=1) restated (third-party => parity unpinned): inputs
+// reflect-padded by 5, 11x11 gaussian (sigma 1.5) 'valid' filter of {p, t, p^2, t^2, pt}, variances clamped at 0, the
+// 5-pixel border of the SSIM map cropped, mean over everything.  extrema are constants w.r.t. the gradient (detached).
+// Stock ATen runs ~50 launches forward and ~80 backward for this; here 6 + 3, all HBM-bound streaming passes over the
+// [B*C] planes:  stats -> finish -> stack (normalise + reflect pad + products) -> gauss11 -> SSIM map reduce -> combine;
+// backward: dS/d{mu_p, E_pp, E_pt} -> gauss11 adjoint -> input gradient (reflect-pad adjoint + the MSE terms).
+#include "common.h"
+
+namespace {
+
+constexpr int PAD = 5;
+constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f, EPS = 1e-8f;
+// stats[]: 0 sum (P-T)^2, 1 sum (P-T)^2 e^{2T}, 2 min P, 3 max P, 4 min T, 5 max T, 6 sum SSIM map, 7 loss
+
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void hl_stats_kernel(const float* __restrict__ P, const float* __restrict__ T, float* __restrict__ part,
+                                                       size_t total) {
+    __shared__ float red[4][6];
+    float s0 = 0.f, s1 = 0.f, pmin = INFINITY, pmax = -INFINITY, tmin = INFINITY, tmax = -INFINITY;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const float p = P[e], t = T[e], d = p - t, q = d * d;
+        s0 += q;
+        s1 += q * __expf(2.f * t);
+        pmin = fminf(pmin, p), pmax = fmaxf(pmax, p), tmin = fminf(tmin, t), tmax = fmaxf(tmax, t);
+    }
+    s0 = kmu::wave_sum(s0), s1 = kmu::wave_sum(s1);
+    pmax = kmu::wave_max(pmax), tmax = kmu::wave_max(tmax);
+    pmin = -kmu::wave_max(-pmin), tmin = -kmu::wave_max(-tmin);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = pmin, red[wave][3] = pmax, red[wave][4] = tmin, red[wave][5] = tmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = part + (size_t)blockIdx.x * 6;
+        o[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        o[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        o[2] = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
+        o[3] = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+        o[4] = fminf(fminf(red[0][4], red[1][4]), fminf(red[2][4], red[3][4]));
+        o[5] = fmaxf(fmaxf(red[0][5], red[1][5]), fmaxf(red[2][5], red[3][5]));
+    }
+}
+
+// one workgroup: fold the per-block partials in a fixed order.  mode 0: the 6 statistics -> stats[0..5];
+// mode 1: SSIM-map partial sums -> stats[6] and the loss -> stats[7]
+__global__ __launch_bounds__(256) void hl_finish_kernel(const float* __restrict__ part, int nblk, float* __restrict__ stats, int mode,
+                                                        float alpha, float inv_nel, float inv_nmap) {
+    __shared__ float red[256][6];
+    const int t = threadIdx.x;
+    if (mode == 0) {
+        float v[6] = {0.f, 0.f, INFINITY, -INFINITY, INFINITY, -INFINITY};
+        for (int b = t; b < nblk; b += 256) {
+            const float* p = part + (size_t)b * 6;
+            v[0] += p[0], v[1] += p[1];
+            v[2] = fminf(v[2], p[2]), v[3] = fmaxf(v[3], p[3]), v[4] = fminf(v[4], p[4]), v[5] = fmaxf(v[5], p[5]);
+        }
+        for (int k = 0; k < 6; ++k) red[t][k] = v[k];
+        __syncthreads();
+        if (t < 6) {
+            float a = red[0][t];
+            for (int i = 1; i < 256; ++i) a = t < 2 ? a + red[i][t] : ((t & 1) ? fmaxf(a, red[i][t]) : fminf(a, red[i][t]));
+            stats[t] = a;
+        }
+    } else {
+        float s = 0.f;
+        for (int b = t; b < nblk; b += 256) s += part[b];
+        red[t][0] = s;
+        __syncthreads();
+        if (t == 0) {
+            float a = 0.f;
+            for (int i = 0; i < 256; ++i) a += red[i][0];
+            stats[6] = a;
+            stats[7] = alpha * (0.55f * stats[0] * inv_nel + 0.45f * stats[1] * inv_nel) + (1.f - alpha) * (1.f - a * inv_nmap);
+        }
+    }
+}
+
+// stack[k][n][Y][X] over the padded (H+10)x(W+10) domain, k = p, t, p^2, t^2, pt of the normalised values
+__global__ __launch_bounds__(256) void hl_stack_kernel(const float* __restrict__ P, const float* __restrict__ T,
+                                                       const float* __restrict__ stats, float* __restrict__ stack, int N, int H, int W) {
+    const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
+    const size_t plane = (size_t)Hp * Wp, total = (size_t)N * plane;
+    const float pmin = stats[2], dp = stats[3] - stats[2] + EPS, tmin = stats[4], dt = stats[5] - stats[4] + EPS;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t n = e / plane;
+        const int r = (int)(e - n * plane), Y = r / Wp, X = r - Y * Wp;
+        const size_t src = (n * H + reflect(Y - PAD, H)) * W + reflect(X - PAD, W);
+        const float p = (P[src] - pmin) / dp, t = (T[src] - tmin) / dt;
+        stack[e] = p;
+        stack[total + e] = t;
+        stack[2 * total + e] = p * p;
+        stack[3 * total + e] = t * t;
+        stack[4 * total + e] = p * t;
+    }
+}
+
+struct Ssim {
+    float S, dmu, dpp, dpt;
+};
+__device__ __forceinline__ Ssim ssim_at(float mp, float mt, float epp, float ett, float ept) {
+    const float vp = epp - mp * mp, vt = ett - mt * mt;
+    const float gp = vp >= 0.f ? 1.f : 0.f;
+    const float spp = fmaxf(vp, 0.f), stt = fmaxf(vt, 0.f), spt = ept - mp * mt;
+    const float A1 = 2.f * mp * mt + C1, A2 = 2.f * spt + C2, B1 = mp * mp + mt * mt + C1, B2 = spp + stt + C2;
+    const float ib = 1.f / (B1 * B2);
+    Ssim r;
+    r.S = A1 * A2 * ib;
+    r.dpt = 2.f * A1 * ib;
+    r.dpp = -r.S / B2 * gp;
+    r.dmu = 2.f * mt * (A2 - A1) * ib - 2.f * mp * r.S / B1 + 2.f * mp * gp * r.S / B2;
+    return r;
+}
+
+// filt[k][n][H][W]: sum of the SSIM map over the cropped interior -> per-block partials
+__global__ __launch_bounds__(256) void hl_ssim_reduce_kernel(const float* __restrict__ filt, float* __restrict__ part, int N, int H, int W) {
+    __shared__ float red[4];
+    const int Hc = H - 2 * PAD, Wc = W - 2 * PAD;
+    const size_t plane = (size_t)H * W, all = (size_t)N * plane, total = (size_t)N * Hc * Wc;
+    float s = 0.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t n = e / ((size_t)Hc * Wc);
+        const int r = (int)(e - n * Hc * Wc), y = r / Wc + PAD, x = r % Wc + PAD;
+        const size_t i = n * plane + (size_t)y * W + x;
+        s += ssim_at(filt[i], filt[all + i], filt[2 * all + i], filt[3 * all + i], filt[4 * all + i]).S;
+    }
+    s = kmu::wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// gmaps[k][n][H][W], k = d loss / d {mu_p, E_pp, E_pt} (zero outside the cropped interior); coef = -g (1-a) / n_map
+__global__ __launch_bounds__(256) void hl_ssim_grad_kernel(const float* __restrict__ filt, const float* __restrict__ gout,
+                                                           float* __restrict__ gmaps, int N, int H, int W, float coef) {
+    const size_t plane = (size_t)H * W, all = (size_t)N * plane;
+    const float g = gout[0] * coef;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < all; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e % plane), y = r / W, x = r - y * W;
+        float a = 0.f, b = 0.f, c = 0.f;
+        if (y >= PAD && y < H - PAD && x >= PAD && x < W - PAD) {
+            const Ssim v = ssim_at(filt[e], filt[all + e], filt[2 * all + e], filt[3 * all + e], filt[4 * all + e]);
+            a = g * v.dmu, b = g * v.dpp, c = g * v.dpt;
+        }
+        gmaps[e] = a;
+        gmaps[all + e] = b;
+        gmaps[2 * all + e] = c;
+    }
+}
+
+// q[k][n][Hp][Wp] = adjoint-filtered gmaps.  dP = (sum over the reflect images of (q_mu + 2 pn q_pp + tn q_pt)) / (max-min+eps)
+//                                                + g a (2 (P-T) / nel) (0.55 + 0.45 e^{2T})
+__global__ __launch_bounds__(256) void hl_grad_input_kernel(const float* __restrict__ P, const float* __restrict__ T,
+                                                            const float* __restrict__ stats, const float* __restrict__ q,
+                                                            const float* __restrict__ gout, float* __restrict__ dP, int N, int H, int W,
+                                                            float alpha, float inv_nel) {
+    const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
+    const size_t plane = (size_t)H * W, total = (size_t)N * plane, pplane = (size_t)Hp * Wp, pall = (size_t)N * pplane;
+    const float pmin = stats[2], dp = stats[3] - stats[2] + EPS, tmin = stats[4], dt = stats[5] - stats[4] + EPS;
+    const float g = gout[0];
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t n = e / plane;
+        const int r = (int)(e - n * plane), y = r / W, x = r - y * W;
+        const float p = P[e], t = T[e], pn = (p - pmin) / dp, tn = (t - tmin) / dt;
+        // padded-domain positions whose reflect-source is (y, x): the pixel itself plus its mirror images in the 5-wide border
+        int ys[2] = {y + PAD, -1}, xs[2] = {x + PAD, -1};
+        if (y >= 1 && y <= PAD) ys[1] = PAD - y;
+        else if (y >= H - 1 - PAD && y <= H - 2) ys[1] = 2 * H - 2 - y + PAD;
+        if (x >= 1 && x <= PAD) xs[1] = PAD - x;
+        else if (x >= W - 1 - PAD && x <= W - 2) xs[1] = 2 * W - 2 - x + PAD;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (ys[a] < 0 || xs[b] < 0) continue;
+                const size_t i = n * pplane + (size_t)ys[a] * Wp + xs[b];
+                acc += q[i] + 2.f * pn * q[pall + i] + tn * q[2 * pall + i];
+            }
+        const float d = p - t;
+        dP[e] = acc / dp + g * alpha * 2.f * d * inv_nel * (0.55f + 0.45f * __expf(2.f * t));
+    }
+}
+
+inline unsigned grid_for(size_t n, unsigned cap) {
+    const size_t b = (n + 255) / 256;
+    return (unsigned)(b > cap ? cap : (b ? b : 1));
+}
+
+int check(const char* what, int N, int H, int W) {
+    KMU_REQUIRE(N > 0 && H > 2 * PAD + 1 && W > 2 * PAD + 1, "%s: planes of %dx%d are too small for the 11x11 SSIM window and its border crop", what,
+                H, W);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int kmu_hybrid_loss_blocks(int N, int H, int W) { return (int)grid_for((size_t)N * H * W, 1024); }
+
+extern "C" int kmu_hybrid_loss_stats(const float* pred, const float* target, float* part, float* stats, int N, int H, int W,
+                                     kmu_stream_t stream) {
+    KMU_REQUIRE(pred && target && part && stats, "hybrid_loss_stats: null pointer");
+    if (int rc = check("hybrid_loss_stats", N, H, W)) return rc;
+    const size_t total = (size_t)N * H * W;
+    const int nblk = kmu_hybrid_loss_blocks(N, H, W);
+    hipLaunchKernelGGL(hl_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, pred, target, part, total);
+    hipLaunchKernelGGL(hl_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk, stats, 0, 0.f, 0.f, 0.f);
+    return kmu::launch_status("hybrid_loss_stats");
+}
+
+extern "C" int kmu_hybrid_loss_stack(const float* pred, const float* target, const float* stats, float* stack, int N, int H, int W,
+                                     kmu_stream_t stream) {
+    KMU_REQUIRE(pred && target && stats && stack, "hybrid_loss_stack: null pointer");
+    if (int rc = check("hybrid_loss_stack", N, H, W)) return rc;
+    const size_t total = (size_t)N * (H + 2 * PAD) * (W + 2 * PAD);
+    hipLaunchKernelGGL(hl_stack_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, pred, target, stats, stack, N, H, W);
+    return kmu::launch_status("hybrid_loss_stack");
+}
+
+extern "C" int kmu_hybrid_loss_combine(const float* filt, float* part, float* stats, int N, int H, int W, float alpha, kmu_stream_t stream) {
+    KMU_REQUIRE(filt && part && stats, "hybrid_loss_combine: null pointer");
+    if (int rc = check("hybrid_loss_combine", N, H, W)) return rc;
+    const size_t nmap = (size_t)N * (H - 2 * PAD) * (W - 2 * PAD);
+    const int nblk = kmu_hybrid_loss_blocks(N, H, W);
+    hipLaunchKernelGGL(hl_ssim_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, filt, part, N, H, W);
+    hipLaunchKernelGGL(hl_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk, stats, 1, alpha,
+                       1.f / (float)((size_t)N * H * W), 1.f / (float)nmap);
+    return kmu::launch_status("hybrid_loss_combine");
+}
+
+extern "C" int kmu_hybrid_loss_grad_maps(const float* filt, const float* gout, float* gmaps, int N, int H, int W, float alpha,
+                                         kmu_stream_t stream) {
+    KMU_REQUIRE(filt && gout && gmaps, "hybrid_loss_grad_maps: null pointer");
+    if (int rc = check("hybrid_loss_grad_maps", N, H, W)) return rc;
+    const size_t nmap = (size_t)N * (H - 2 * PAD) * (W - 2 * PAD);
+    hipLaunchKernelGGL(hl_ssim_grad_kernel, dim3(grid_for((size_t)N * H * W, 8192)), dim3(256), 0, (hipStream_t)stream, filt, gout, gmaps, N,
+                       H, W, -(1.f - alpha) / (float)nmap);
+    return kmu::launch_status("hybrid_loss_grad_maps");
+}
+
+extern "C" int kmu_hybrid_loss_grad_input(const float* pred, const float* target, const float* stats, const float* q, const float* gout,
+                                          float* dpred, int N, int H, int W, float alpha, kmu_stream_t stream) {
+    KMU_REQUIRE(pred && target && stats && q && gout && dpred, "hybrid_loss_grad_input: null pointer");
+    if (int rc = check("hybrid_loss_grad_input", N, H, W)) return rc;
+    hipLaunchKernelGGL(hl_grad_input_kernel, dim3(grid_for((size_t)N * H * W, 8192)), dim3(256), 0, (hipStream_t)stream, pred, target, stats,
+                       q, gout, dpred, N, H, W, alpha, 1.f / (float)((size_t)N * H * W));
+    return kmu::launch_status("hybrid_loss_grad_input");
+}

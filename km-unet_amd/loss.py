@@ -1,6 +1,7 @@
 """HybridLoss of the reference training loop (train_shanghai.py:298-325) and the CSI / POD / FAR / HSS
-contingency scores of its evaluator (metrics.py:45-47,105-114,220-288), as device-side PyTorch-ROCm ops
-(these are callers either side of the hot path, SURVEY.md 8f -- not hand-written kernels).
+contingency scores of its evaluator (metrics.py:45-47,105-114,220-288) on the device (callers either side of the hot path,
+SURVEY.md 8f).  On the GPU HybridLoss runs as the fused kernels of csrc/hybrid_loss.hip + csrc/gauss11.hip; the tensor-op
+formulation below is the same arithmetic and serves CPU tensors, other window sizes and targets that need a gradient.
 
 SSIM: torchmetrics' StructuralSimilarityIndexMeasure(data_range=1.0) is third-party and not available here; its
 published defaults are restated (gaussian 11x11, sigma 1.5, k1 .01, k2 .03, reflect pad 5, border cropped).  The
@@ -46,6 +47,9 @@ class HybridLoss(nn.Module):
         return smap.reshape(b, -1).mean(-1).mean()
 
     def forward(self, pred, target):
+        if pred.is_cuda and self.k == 11 and min(pred.shape[-2:]) >= 12 and not target.requires_grad:
+            from . import ops
+            return ops.hybrid_loss(pred, target, self.gauss, self.alpha)      # fused: 6 launches forward, 3 backward
         d = pred - target
         sq = d * d
         mse = sq.mean()

@@ -577,6 +577,56 @@ def gauss11(x, taps):
     return Gauss11Fn.apply(x, taps)
 
 
+class HybridLossFn(torch.autograd.Function):
+    """train_shanghai.py:298-325 as 6 launches forward / 3 backward (csrc/hybrid_loss.hip + the gauss11 window)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, taps, alpha):
+        lib = _lib.load()
+        pred, target = _f32c(pred, "pred"), _f32c(target, "target")
+        if pred.shape != target.shape or pred.dim() != 4:
+            raise RuntimeError("hybrid_loss: pred %s and target %s must be equal-shaped [B,C,H,W]" % (tuple(pred.shape), tuple(target.shape)))
+        B, C, H, W = pred.shape
+        N, dev, st = B * C, pred.device, _stream()
+        part = torch.empty(6 * lib.kmu_hybrid_loss_blocks(N, H, W), device=dev, dtype=torch.float32)
+        stats = torch.empty(8, device=dev, dtype=torch.float32)
+        _lib.check(_call(("hybrid_loss_stats", (N, H, W)), lib.kmu_hybrid_loss_stats, _ptr(pred), _ptr(target), _ptr(part), _ptr(stats), N, H,
+                         W, st), "kmu_hybrid_loss_stats")
+        stack = torch.empty(5, N, H + 10, W + 10, device=dev, dtype=torch.float32)
+        _lib.check(_call(("hybrid_loss_stack", (N, H, W)), lib.kmu_hybrid_loss_stack, _ptr(pred), _ptr(target), _ptr(stats), _ptr(stack), N, H,
+                         W, st), "kmu_hybrid_loss_stack")
+        filt = torch.empty(5, N, H, W, device=dev, dtype=torch.float32)
+        _lib.check(_call(("gauss11_filter", (5 * N, H + 10, W + 10)), lib.kmu_gauss11_filter, _ptr(stack), _ptr(taps), _ptr(filt), 5 * N,
+                         H + 10, W + 10, 0, st), "kmu_gauss11_filter")
+        _lib.check(_call(("hybrid_loss_combine", (N, H, W)), lib.kmu_hybrid_loss_combine, _ptr(filt), _ptr(part), _ptr(stats), N, H, W,
+                         float(alpha), st), "kmu_hybrid_loss_combine")
+        ctx.save_for_backward(pred, target, stats, filt, taps)
+        ctx.alpha = float(alpha)
+        return stats[7].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        pred, target, stats, filt, taps = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        N, dev, st = B * C, pred.device, _stream()
+        g = _f32c(g, "grad").reshape(1)
+        gmaps = torch.empty(3, N, H, W, device=dev, dtype=torch.float32)
+        _lib.check(_call(("hybrid_loss_grad_maps", (N, H, W)), lib.kmu_hybrid_loss_grad_maps, _ptr(filt), _ptr(g), _ptr(gmaps), N, H, W,
+                         ctx.alpha, st), "kmu_hybrid_loss_grad_maps")
+        q = torch.empty(3, N, H + 10, W + 10, device=dev, dtype=torch.float32)
+        _lib.check(_call(("gauss11_adjoint", (3 * N, H, W)), lib.kmu_gauss11_filter, _ptr(gmaps), _ptr(taps), _ptr(q), 3 * N, H, W, 1, st),
+                   "kmu_gauss11_filter")
+        dpred = torch.empty_like(pred)
+        _lib.check(_call(("hybrid_loss_grad_input", (N, H, W)), lib.kmu_hybrid_loss_grad_input, _ptr(pred), _ptr(target), _ptr(stats), _ptr(q),
+                         _ptr(g), _ptr(dpred), N, H, W, ctx.alpha, st), "kmu_hybrid_loss_grad_input")
+        return dpred, None, None, None
+
+
+def hybrid_loss(pred, target, taps, alpha=0.7):
+    return HybridLossFn.apply(pred, target, taps, alpha)
+
+
 # ------------------------------------------------------------------------------------------ BN + ReLU + blend
 class BnBlendFn(torch.autograd.Function):
     """out = x + sigmoid(alpha[row]) * (f(t) - x),  f = relu?(BatchNorm2d(t)) or identity

@@ -116,6 +116,27 @@ def test_hybrid_loss_and_csi_vs_oracle():
             assert (a != a and b != b) or abs(a - b) < 1e-12, (th, k, a, b)
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 12, 17), (3, 2, 40, 24), (8, 5, 128, 128)])
+def test_fused_hybrid_loss_vs_oracle(shape):
+    """csrc/hybrid_loss.hip (+ gauss11) against the CPU oracle restatement of train_shanghai.py:298-325: value and dL/dpred,
+    at the smallest legal plane (12 = window + crop), a ragged one and the bench shape; upstream gradient != 1."""
+    from km_unet_amd.loss import HybridLoss
+    from oracle.loss import hybrid_loss
+    gen = torch.Generator().manual_seed(sum(shape))
+    pred = (torch.rand(*shape, generator=gen) * 0.8 + 0.1).requires_grad_(True)
+    tgt = torch.rand(*shape, generator=gen)
+    (hybrid_loss(pred, tgt) * 1.7).backward()
+    lo = hybrid_loss(pred, tgt).item()
+    pd = pred.detach().cuda().requires_grad_(True)
+    crit = HybridLoss().cuda()
+    lg = crit(pd, tgt.cuda())
+    (lg * 1.7).backward()
+    print("  [fused hybrid_loss %s] value %.2e grad %.2e" % (shape, abs(lg.item() - lo) / abs(lo), rel_err(pd.grad, pred.grad)))
+    assert abs(lg.item() - lo) < 2e-5 * abs(lo) and rel_err(pd.grad, pred.grad) < TOL
+    again = crit(pd.detach(), tgt.cuda())
+    assert again.item() == lg.item()          # deterministic reductions
+
+
 @pytest.mark.gpu
 def test_graph_replay_matches_eager_across_host_sync():
     """hipGraph replay of the whole train step (HybridLoss + DropPath + AdamW) must keep computing the step after the
