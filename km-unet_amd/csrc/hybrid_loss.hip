@@ -44,37 +44,39 @@ __global__ __launch_bounds__(256) void hl_stats_kernel(const float* __restrict__
     }
 }
 
-// one workgroup: fold the per-block partials in a fixed order.  mode 0: the 6 statistics -> stats[0..5];
-// mode 1: SSIM-map partial sums -> stats[6] and the loss -> stats[7]
+// one workgroup: fold the per-block partials (strided per thread, then an LDS tree: fixed order => deterministic).
+// mode 0: the 6 statistics -> stats[0..5];  mode 1: SSIM-map partial sums -> stats[6] and the loss -> stats[7]
 __global__ __launch_bounds__(256) void hl_finish_kernel(const float* __restrict__ part, int nblk, float* __restrict__ stats, int mode,
                                                         float alpha, float inv_nel, float inv_nmap) {
-    __shared__ float red[256][6];
+    __shared__ float red[6][256];
     const int t = threadIdx.x;
+    float v[6] = {0.f, 0.f, INFINITY, -INFINITY, INFINITY, -INFINITY};
     if (mode == 0) {
-        float v[6] = {0.f, 0.f, INFINITY, -INFINITY, INFINITY, -INFINITY};
         for (int b = t; b < nblk; b += 256) {
             const float* p = part + (size_t)b * 6;
             v[0] += p[0], v[1] += p[1];
             v[2] = fminf(v[2], p[2]), v[3] = fmaxf(v[3], p[3]), v[4] = fminf(v[4], p[4]), v[5] = fmaxf(v[5], p[5]);
         }
-        for (int k = 0; k < 6; ++k) red[t][k] = v[k];
-        __syncthreads();
-        if (t < 6) {
-            float a = red[0][t];
-            for (int i = 1; i < 256; ++i) a = t < 2 ? a + red[i][t] : ((t & 1) ? fmaxf(a, red[i][t]) : fminf(a, red[i][t]));
-            stats[t] = a;
-        }
     } else {
-        float s = 0.f;
-        for (int b = t; b < nblk; b += 256) s += part[b];
-        red[t][0] = s;
+        for (int b = t; b < nblk; b += 256) v[0] += part[b];
+    }
+    const int nv = mode == 0 ? 6 : 1;
+    for (int k = 0; k < nv; ++k) red[k][t] = v[k];
+    __syncthreads();
+    for (int half = 128; half > 0; half >>= 1) {
+        if (t < half)
+            for (int k = 0; k < nv; ++k) {
+                const float a = red[k][t], c = red[k][t + half];
+                red[k][t] = k < 2 ? a + c : ((k & 1) ? fmaxf(a, c) : fminf(a, c));
+            }
         __syncthreads();
-        if (t == 0) {
-            float a = 0.f;
-            for (int i = 0; i < 256; ++i) a += red[i][0];
-            stats[6] = a;
-            stats[7] = alpha * (0.55f * stats[0] * inv_nel + 0.45f * stats[1] * inv_nel) + (1.f - alpha) * (1.f - a * inv_nmap);
-        }
+    }
+    if (mode == 0) {
+        if (t < 6) stats[t] = red[t][0];
+    } else if (t == 0) {
+        const float a = red[0][0];
+        stats[6] = a;
+        stats[7] = alpha * (0.55f * stats[0] * inv_nel + 0.45f * stats[1] * inv_nel) + (1.f - alpha) * (1.f - a * inv_nmap);
     }
 }
 

@@ -8,7 +8,8 @@ import sys
 
 def category(n):
     if "anonymous namespace)::" in n and any(k in n for k in ("hsm_", "kan_", "bn_", "dwconv", "ln1d", "gn_", "qkv", "dysample",
-                                                              "deform", "pw_", "colsum")):
+                                                              "deform", "pw_", "colsum", "gate_mlp", "mix3", "iwp_", "gauss11",
+                                                              "shift3", "hl_")):
         return "hand-written HIP"
     if n.startswith("Cijk"):
         return "GEMM (hipBLASLt/rocBLAS)"
