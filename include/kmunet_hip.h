@@ -177,6 +177,9 @@ int kmu_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, fl
                       kmu_stream_t stream);
 int kmu_dwconv3x3_bwd_data(const float* dy, const float* weight, float* dx, int B, int C, int H, int W,
                            kmu_stream_t stream);
+/* dx = dwconv3x3^T(dy) + addend (same purpose as kmu_pwconv_bwd_input_add) */
+int kmu_dwconv3x3_bwd_data_add(const float* dy, const float* weight, const float* addend, float* dx, int B, int C, int H, int W,
+                               kmu_stream_t stream);
 int kmu_dwconv3x3_partials(int B);
 int kmu_dwconv3x3_bwd_weight(const float* x, const float* dy, float* d_weight_partial, float* d_bias_partial, int B,
                              int C, int H, int W, kmu_stream_t stream);
@@ -224,6 +227,10 @@ int kmu_pwconv_fwd(const float* x, const float* w, const float* bias, float* y, 
                    kmu_stream_t stream);
 int kmu_pwconv_bwd_input(const float* gy, const float* w, const float* x_pre, float* dx, int B, int Ci, int Co, int P,
                          int act_in, kmu_stream_t stream);
+/* dx = W^T * gy + addend  (addend [B,Ci,P]: the gradient that reaches the same tensor along another path, e.g. the blend
+ * partner of EfficientViMBlock's FFN stage -- saves autograd's separate fan-in add) */
+int kmu_pwconv_bwd_input_add(const float* gy, const float* w, const float* addend, float* dx, int B, int Ci, int Co, int P,
+                             kmu_stream_t stream);
 size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P);
 int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci,
                           int Co, int P, int act_in, kmu_stream_t stream);

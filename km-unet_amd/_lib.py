@@ -76,6 +76,8 @@ SIGNATURES = {
     "kmu_group_norm_bwd": (_I, [_P] * 8 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_fwd": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_bwd_data": (_I, [_P] * 3 + [_I] * 4 + [_P]),
+    "kmu_dwconv3x3_bwd_data_add": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "kmu_pwconv_bwd_input_add": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_partials": (_I, [_I]),
     "kmu_dwconv3x3_bwd_weight": (_I, [_P] * 4 + [_I] * 4 + [_P]),
 }

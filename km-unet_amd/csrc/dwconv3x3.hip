@@ -20,7 +20,8 @@ constexpr int WSPLIT = 4;  // row splits per (b, c) plane in the weight-gradient
 
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
-                                                        float* __restrict__ out, int C, int H, int W, int flip, size_t total) {
+                                                        const float* __restrict__ addend, float* __restrict__ out, int C, int H,
+                                                        int W, int flip, size_t total) {
     const int W4 = (W + 3) >> 2;
     const bool vec_ok = (W & 3) == 0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -62,6 +63,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
             const float sc = scale[r];
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] *= sc;
+        }
+        if (addend) {                       // e.g. the blend partner's gradient: saves autograd's separate fan-in add
+            const float* ap = addend + (r * H + y) * (size_t)W + x0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (x0 + q < W) acc[q] += ap[q];
         }
         float* dst = out + (r * H + y) * (size_t)W + x0;
         if (vec_ok) {
@@ -182,11 +189,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_scaled_finish_kernel(const floa
 }
 
 int launch_stencil(const float* in, const float* w, const float* bias, const float* scale, float* out, int B, int C, int H, int W,
-                   int flip, hipStream_t st, const char* what) {
+                   int flip, hipStream_t st, const char* what, const float* addend = nullptr) {
     const size_t total = (size_t)B * C * H * ((W + 3) / 4);
     size_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, scale, out, C, H, W, flip, total);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, scale, addend, out, C, H, W, flip, total);
     return kmu::launch_status(what);
 }
 
@@ -241,4 +248,11 @@ extern "C" int kmu_dwconv3x3_scaled_finish(const float* d_weight_partial, const 
     hipLaunchKernelGGL(dwconv3x3_scaled_finish_kernel, dim3(kmu::cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, d_weight_partial,
                        d_bias_partial, scale, weight, bias, d_weight, d_bias, d_scale, B, C);
     return kmu::launch_status("dwconv3x3_scaled_finish");
+}
+
+extern "C" int kmu_dwconv3x3_bwd_data_add(const float* dy, const float* weight, const float* addend, float* dx, int B, int C, int H, int W,
+                                          kmu_stream_t stream) {
+    KMU_REQUIRE(dy && weight && addend && dx, "dwconv3x3_bwd_data_add: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_bwd_data_add: bad dims");
+    return launch_stencil(dy, weight, nullptr, nullptr, dx, B, C, H, W, 1, (hipStream_t)stream, "dwconv3x3_bwd_data_add", addend);
 }

@@ -41,8 +41,8 @@ __host__ __device__ inline int lds_stride(int nt) { return (16 * nt) % 32 == 16 
 template <int NT>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w, long w_sn,
                                                       long w_sk, const float* __restrict__ bias,
-                                                      const float* __restrict__ mul_pre, float* __restrict__ y, int K, int N,
-                                                      int P, int act_in) {
+                                                      const float* __restrict__ mul_pre, const float* __restrict__ addend,
+                                                      float* __restrict__ y, int K, int N, int P, int act_in) {
     extern __shared__ float wl[];
     constexpr int S = (16 * NT) % 32 == 16 ? 16 * NT : 16 * NT + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] *= gelu_grad_f(z[t]);
             }
+            if (addend) o += *reinterpret_cast<const floatx4*>(addend + off + 16 * i);
             *reinterpret_cast<floatx4*>(y + off + 16 * i) = o;
         }
     }
@@ -296,26 +297,26 @@ inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
 }
 
 template <int NT>
-int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y, int B,
-                int K, int N, int P, int act_in, hipStream_t st) {
+int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, const float* addend,
+                float* y, int B, int K, int N, int P, int act_in, hipStream_t st) {
     const size_t lds = (size_t)K * lds_stride(NT) * sizeof(float);
     KMU_MAX_LDS((pw_gemm_kernel<NT>), lds);
     hipLaunchKernelGGL((pw_gemm_kernel<NT>), dim3(B * ((P + 255) / 256), N / (16 * NT)), dim3(256), lds, st, x, w, w_sn, w_sk, bias,
-                       mul_pre, y, K, N, P, act_in);
+                       mul_pre, addend, y, K, N, P, act_in);
     return 0;
 }
 
 int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y,
-         int B, int K, int N, int P, int act_in, hipStream_t st) {
+         int B, int K, int N, int P, int act_in, hipStream_t st, const float* addend = nullptr) {
     KMU_REQUIRE(B > 0 && K > 0 && N > 0 && K % 16 == 0 && N % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16",
                 what, K, N);
     KMU_REQUIRE(P > 0 && P % 64 == 0, "%s: H*W = %d must be a positive multiple of 64", what, P);
     KMU_REQUIRE(K <= 256, "%s: %d contraction channels exceed the LDS weight tile (256)", what, K);
     switch (pick_tiles(N / 16)) {
-        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
-        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
-        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
-        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, y, B, K, N, P, act_in, st); break;
+        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
+        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
+        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
+        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
     }
     return kmu::launch_status(what);
 }
@@ -352,6 +353,12 @@ extern "C" int kmu_pwconv_bwd_input(const float* gy, const float* w, const float
     KMU_REQUIRE(!act_in || x_pre, "pwconv_bwd_input: act_in needs the pre-activation input");
     // dx[ci] = sum_co W[co][ci] gy[co]: the same contraction with K = Co, N = Ci and w(n = ci, k = co) = W[k*Ci + n]
     return gemm("pwconv_bwd_input", gy, w, 1, Ci, nullptr, act_in ? x_pre : nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream);
+}
+
+extern "C" int kmu_pwconv_bwd_input_add(const float* gy, const float* w, const float* addend, float* dx, int B, int Ci, int Co, int P,
+                                        kmu_stream_t stream) {
+    KMU_REQUIRE(gy && w && addend && dx, "pwconv_bwd_input_add: null pointer");
+    return gemm("pwconv_bwd_input_add", gy, w, 1, Ci, nullptr, nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream, addend);
 }
 
 extern "C" size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P) {

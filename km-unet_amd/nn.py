@@ -267,6 +267,15 @@ class EfficientViMBlock(nn.Module):
             x = torch.lerp(x, self.dwconv2(x), a[2])
             return torch.lerp(x, self.ffn(x), a[3])
         a0, a1, a2, a3 = self.alpha.unbind(0)     # one stack() in backward instead of 4 x (zeros + add)
+        b, c, hh, ww = x.shape
+        if "evim_composite" not in _TORCH_GLUE and "dwconv" not in _TORCH_GLUE and "pwconv" not in _TORCH_GLUE \
+                and ops.pwconv_supported(c, self.ffn.fc1.conv.out_channels, hh * ww):
+            # each stage as ONE autograd node: its backward folds the blend partner's gradient into the branch's last kernel
+            x = ops.dw_bn_blend(x, self.dwconv1.conv, self.dwconv1.norm, a0)
+            y, _ = self.mixer(self.norm(x.flatten(2)))
+            x = ops.bn_blend(y, x, None, a1)
+            x = ops.dw_bn_blend(x, self.dwconv2.conv, self.dwconv2.norm, a2)
+            return ops.ffn_blend(x, self.ffn.fc1, self.ffn.fc2, a3)
         x = ops.bn_blend(self.dwconv1.conv_only(x), x, self.dwconv1.norm, a0)
         y, _ = self.mixer(self.norm(x.flatten(2)))
         x = ops.bn_blend(y, x, None, a1)

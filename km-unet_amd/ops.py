@@ -685,6 +685,152 @@ def bn_blend(t, x=None, bn=None, alpha=None, row=0, relu=False):
     return BnBlendFn.apply(t, x, bn.weight, bn.bias, a_row, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, training, nbt)
 
 
+# ------------------------------------------------------------------------------------------ EfficientViMBlock stages
+# Composite stages  out = x + sigmoid(a) (f(x) - x)  with f = BN(dwconv3x3(x)) or f = BN(fc2(ReLU(BN(fc1(x))))).
+# As separate autograd nodes, x receives two full-size gradients (through f and through the blend) that the engine sums
+# with one `add` kernel per stage (45 per step for these two stage types); here the last backward kernel of the f branch
+# (depthwise backward-data / fc1's input gradient) adds the blend gradient in its epilogue.
+def _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, relu, training, nbt):
+    B, C = t.shape[:2]
+    HW = t.numel() // (B * C)
+    out = torch.empty_like(t)
+    S = lib.kmu_bn_blend_splits(B, HW)
+    stats = torch.empty(C, 2, device=t.device, dtype=torch.float32)
+    ws = torch.empty(C * S * 3, device=t.device, dtype=torch.float32)
+    _lib.check(_call(("bn_blend_fwd", (B, C, HW)), lib.kmu_bn_blend_fwd, _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row), _ptr(rm),
+                     _ptr(rv), float(momentum), float(eps), int(relu), int(training), _ptr(out), _ptr(stats), _ptr(ws), _ptr(nbt), B, C, HW,
+                     _stream()), "kmu_bn_blend_fwd")
+    return out, stats
+
+
+def _k_bn_bwd(lib, g, t, x, gamma, beta, a_row, stats, relu, training):
+    B, C = t.shape[:2]
+    HW = t.numel() // (B * C)
+    dev = t.device
+    S = lib.kmu_bn_blend_splits(B, HW)
+    dt = torch.empty_like(t)
+    dx = torch.empty_like(t) if a_row is not None else None
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    da = torch.empty(C, device=dev) if a_row is not None else None
+    ws = torch.empty(C * S * 3, device=dev, dtype=torch.float32)
+    _lib.check(_call(("bn_blend_bwd", (B, C, HW)), lib.kmu_bn_blend_bwd, _ptr(g), _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row),
+                     _ptr(stats), int(relu), int(training), _ptr(dt), _ptr(dx), _ptr(dg), _ptr(db), _ptr(da), _ptr(ws), B, C, HW, _stream()),
+               "kmu_bn_blend_bwd")
+    return dt, dx, dg, db, da
+
+
+def _k_pw_fwd(lib, x, w):
+    B, ci, H, W = x.shape
+    co = w.shape[0]
+    y = torch.empty(B, co, H, W, device=x.device, dtype=torch.float32)
+    _lib.check(_call(("pwconv_fwd", (B, ci, co, H * W)), lib.kmu_pwconv_fwd, _ptr(x), _ptr(w), None, _ptr(y), B, ci, co, H * W, 0, _stream()),
+               "kmu_pwconv_fwd")
+    return y
+
+
+def _k_pw_wgrad(lib, x, gy):
+    B, ci, H, W = x.shape
+    co, P = gy.shape[1], H * W
+    nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty(co, ci, device=x.device, dtype=torch.float32)
+    _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight, _ptr(x), _ptr(gy), _ptr(dw), None, _ptr(ws), nbytes, B,
+                     ci, co, P, 0, _stream()), "kmu_pwconv_bwd_weight")
+    return dw
+
+
+class DwBnBlendFn(torch.autograd.Function):
+    """x + sigmoid(a) (BatchNorm2d(dwconv3x3(x)) - x): EfficientViMBlock's dwconv1 / dwconv2 stages
+    (efficient_vim_init.py:85,93) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, w_dw, gamma, beta, a_row, rm, rv, momentum, eps, training, nbt):
+        lib = _lib.load()
+        x, w, a_row = _f32c(x, "x"), _f32c(w_dw, "weight"), _f32c(a_row, "alpha row")
+        B, C, H, W = x.shape
+        t = torch.empty_like(x)
+        _lib.check(_call(("dwconv3x3_fwd", (B, C, H, W)), lib.kmu_dwconv3x3_fwd, _ptr(x), _ptr(w), None, _ptr(t), B, C, H, W, _stream()),
+                   "kmu_dwconv3x3_fwd")
+        out, stats = _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, 0, training, nbt)
+        ctx.save_for_backward(x, w, t, gamma, beta, a_row, stats)
+        ctx.cfg = (int(training), tuple(w_dw.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w, t, gamma, beta, a_row, stats = ctx.saved_tensors
+        training, wshape = ctx.cfg
+        B, C, H, W = x.shape
+        st = _stream()
+        dt, dxb, dg, db, da = _k_bn_bwd(lib, _f32c(g, "grad"), t, x, gamma, beta, a_row, stats, 0, training)
+        dx = torch.empty_like(x)
+        _lib.check(_call(("dwconv3x3_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_data_add, _ptr(dt), _ptr(w), _ptr(dxb), _ptr(dx), B, C, H, W,
+                         st), "kmu_dwconv3x3_bwd_data_add")
+        P = lib.kmu_dwconv3x3_partials(B)
+        dwp = torch.empty(P, C, 9, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dt), _ptr(dwp), None, B, C, H, W, st),
+                   "kmu_dwconv3x3_bwd_weight")
+        (dw,) = colsum(dwp)
+        return dx, dw.view(wshape), dg, db, da, None, None, None, None, None, None
+
+
+class FfnBlendFn(torch.autograd.Function):
+    """x + sigmoid(a) (BN2(fc2(ReLU(BN1(fc1(x))))) - x): EfficientViMBlock's FFN stage (efficient_vim_init.py:96;
+    FFN = two bias-free 1x1 ConvLayer2D, vim_utils_init.py:62-89,122-130) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, mom1, eps1, nbt1, w2, g2, b2, rm2, rv2, mom2, eps2, nbt2, a_row, training):
+        lib = _lib.load()
+        x, a_row = _f32c(x, "x"), _f32c(a_row, "alpha row")
+        hid, C = w1.shape[0], w1.shape[1]
+        w1c, w2c = _f32c(w1, "fc1 weight").view(hid, C), _f32c(w2, "fc2 weight").view(C, hid)
+        z1 = _k_pw_fwd(lib, x, w1c)
+        h, st1 = _k_bn_fwd(lib, z1, None, g1, b1, None, rm1, rv1, mom1, eps1, 1, training, nbt1)
+        z2 = _k_pw_fwd(lib, h, w2c)
+        out, st2 = _k_bn_fwd(lib, z2, x, g2, b2, a_row, rm2, rv2, mom2, eps2, 0, training, nbt2)
+        ctx.save_for_backward(x, w1c, z1, st1, h, w2c, z2, st2, g1, b1, g2, b2, a_row)
+        ctx.cfg = (int(training), tuple(w1.shape), tuple(w2.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w1, z1, st1, h, w2, z2, st2, g1, b1, g2, b2, a_row = ctx.saved_tensors
+        training, s1, s2 = ctx.cfg
+        B, C, H, W = x.shape
+        hid, P, st = w1.shape[0], H * W, _stream()
+        dz2, dxb, dg2, db2, da = _k_bn_bwd(lib, _f32c(g, "grad"), z2, x, g2, b2, a_row, st2, 0, training)
+        dh = torch.empty_like(h)
+        _lib.check(_call(("pwconv_bwd_input", (B, hid, C, P)), lib.kmu_pwconv_bwd_input, _ptr(dz2), _ptr(w2), None, _ptr(dh), B, hid, C, P, 0, st),
+                   "kmu_pwconv_bwd_input")
+        dw2 = _k_pw_wgrad(lib, h, dz2)
+        dz1, _, dg1, db1, _ = _k_bn_bwd(lib, dh, z1, None, g1, b1, None, st1, 1, training)
+        dx = torch.empty_like(x)
+        _lib.check(_call(("pwconv_bwd_input", (B, C, hid, P)), lib.kmu_pwconv_bwd_input_add, _ptr(dz1), _ptr(w1), _ptr(dxb), _ptr(dx), B, C, hid, P,
+                         st), "kmu_pwconv_bwd_input_add")
+        dw1 = _k_pw_wgrad(lib, x, dz1)
+        return (dx, dw1.view(s1), dg1, db1, None, None, None, None, None, dw2.view(s2), dg2, db2, None, None, None, None, None, da, None)
+
+
+def _bn_pack(bn):
+    training = bn.training
+    nbt = bn.num_batches_tracked if training and bn.track_running_stats else None
+    return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, nbt, training
+
+
+def dw_bn_blend(x, conv, bn, a_row):
+    g, b, rm, rv, mom, eps, nbt, training = _bn_pack(bn)
+    return DwBnBlendFn.apply(x, conv.weight, g, b, a_row, rm, rv, mom, eps, training, nbt)
+
+
+def ffn_blend(x, fc1, fc2, a_row):
+    g1, b1, rm1, rv1, mom1, eps1, nbt1, training = _bn_pack(fc1.norm)
+    g2, b2, rm2, rv2, mom2, eps2, nbt2, _ = _bn_pack(fc2.norm)
+    return FfnBlendFn.apply(x, fc1.conv.weight, g1, b1, rm1, rv1, mom1, eps1, nbt1, fc2.conv.weight, g2, b2, rm2, rv2, mom2, eps2, nbt2, a_row,
+                            training)
+
+
 # ------------------------------------------------------------------------------------------ sigmoid(q*k)*v
 class QkvGateFn(torch.autograd.Function):
     """attn = sigmoid(q*k)*v on the packed qkv conv output (DirectionAttention.forward, KM_UNetV3_SH.py:258-261)."""
