@@ -178,3 +178,30 @@ def test_graph_replay_matches_eager_across_host_sync():
             torch.cuda.synchronize()
         vals.append(g(d3).item())
     assert all(0.0 < v < 1.0 for v in vals) and vals[-1] < vals[0], vals
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 path end to end (one process per rank, graph 1 = forward + backward, eager all-reduce of the flat
+    gradient bucket, graph 2 = AdamW), rehearsed with two ranks that share this box's single GPU: gloo instead of RCCL
+    (RCCL refuses two ranks on one device), everything else as in the driver's multi-GPU run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, KMU_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--size", "64", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
+    assert line["launch_mode"] == "hipGraph replay" and 0.0 < line["loss"] <= 1.5 * line["loss_first"] + 1e-3
+    assert line["value"] > 0 and "roofline" in line and "cpu_baseline" not in line
