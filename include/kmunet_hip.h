@@ -301,12 +301,13 @@ int kmu_hybrid_loss_grad_input(const float* pred, const float* target, const flo
 
 /* ------------------------------------------------------------------------------------
  * IntelligentWaveletPoolingModule up to its fusion conv (WPL/iwp.py:124-130; Haar DWT_2D iwp.py:47-113):
- * x [B,C,H,W] (H, W even) -> out [B,C+1,H/2,W/2] = cat[LL, mean over the 3C channels of cat[LH,HL,HH]].  The
+ * x [B,C,H,W] (H, W even) -> out [B,Ct,H/2,W/2] = cat[LL, mean over the 3C channels of cat[LH,HL,HH], zeros]; Ct >= C+1
+ * (channel padding so that fusion_conv can use kmu_pwconv_* with zero weight columns; Ct = C+1 for the exact layout).  The
  * Softmax2d attention over one channel (iwp.py:127) is identically 1, its conv receives an exactly-zero gradient.
- * bwd: gout [B,C+1,H/2,W/2] -> dx [B,C,H,W], written in full.
+ * bwd: gout [B,Ct,H/2,W/2] -> dx [B,C,H,W], written in full (padding channels ignored).
  * ------------------------------------------------------------------------------------ */
-int kmu_iwp_front_fwd(const float* x, float* out, int B, int C, int H, int W, kmu_stream_t stream);
-int kmu_iwp_front_bwd(const float* gout, float* dx, int B, int C, int H, int W, kmu_stream_t stream);
+int kmu_iwp_front_fwd(const float* x, float* out, int B, int C, int Ct, int H, int W, kmu_stream_t stream);
+int kmu_iwp_front_bwd(const float* gout, float* dx, int B, int C, int Ct, int H, int W, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Squeeze-excite gates on pooled vectors:  g = act2(W2 . act1(W1 . p + b1) + b2),  p [B,I], W1 [H,I], W2 [O,H].

@@ -66,8 +66,8 @@ SIGNATURES = {
     "kmu_hybrid_loss_combine": (_I, [_P] * 3 + [_I] * 3 + [_c.c_float, _P]),
     "kmu_hybrid_loss_grad_maps": (_I, [_P] * 3 + [_I] * 3 + [_c.c_float, _P]),
     "kmu_hybrid_loss_grad_input": (_I, [_P] * 6 + [_I] * 3 + [_c.c_float, _P]),
-    "kmu_iwp_front_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
-    "kmu_iwp_front_bwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
+    "kmu_iwp_front_fwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
+    "kmu_iwp_front_bwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
     "kmu_gate_mlp_fwd": (_I, [_P] * 7 + [_I] * 6 + [_P]),
     "kmu_gate_mlp_bwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "kmu_colsum_multi": (_I, [_I, _P, _P, _P, _P, _P]),

@@ -271,8 +271,10 @@ class KM_UNetV3(nn.Module):
 
     def _pyramid(self, fusion, e1, e2, ref):
         size = ref.shape[2:]
-        a = F.interpolate(e1, size=size, mode="bilinear", align_corners=True)
-        b = F.interpolate(e2, size=size, mode="bilinear", align_corners=True)
+        # bilinear resampling with align_corners=True onto the same grid is the identity (every sample lands on a pixel)
+        same = lambda t: tuple(t.shape[2:]) == tuple(size)
+        a = e1 if same(e1) else F.interpolate(e1, size=size, mode="bilinear", align_corners=True)
+        b = e2 if same(e2) else F.interpolate(e2, size=size, mode="bilinear", align_corners=True)
         return fusion([a, b, b])                 # third level is e2 again (KM_UNetV3_SH.py:495,509)
 
     def forward(self, x):

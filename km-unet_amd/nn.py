@@ -389,7 +389,15 @@ class IntelligentWaveletPoolingModule(nn.Module):
     def forward(self, x):
         if "iwp" not in _TORCH_GLUE and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
             # DWT + (identically-1) attention + channel mean + concat: one HIP stencil (csrc/iwp.hip)
-            return conv1x1(ops.iwp_front(x, self.high_freq_conv.weight, self.high_freq_conv.bias), self.fusion_conv)
+            hf, fc = self.high_freq_conv, self.fusion_conv
+            c, co = x.shape[1], fc.out_channels
+            ct = (c + 1 + 15) // 16 * 16
+            if "pwconv" not in _TORCH_GLUE and ops.pwconv_supported(ct, co, (x.shape[2] // 2) * (x.shape[3] // 2)):
+                # C+1 input channels padded to a multiple of 16 (zero channels x zero weight columns) => pointwise-conv kernels
+                # instead of the strided-batched GEMM path (whose weight gradient ran 113 us per module on rocBLAS)
+                w = F.pad(fc.weight, (0, 0, 0, 0, 0, ct - (c + 1)))
+                return ops.pwconv(ops.iwp_front(x, hf.weight, hf.bias, ct), w, fc.bias)
+            return conv1x1(ops.iwp_front(x, hf.weight, hf.bias), fc)
         ll, lh, hl, hh = self.dwt(x)
         high = torch.cat([lh, hl, hh], dim=1)
         high = high * self.softmax(conv1x1(high, self.high_freq_conv))

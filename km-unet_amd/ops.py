@@ -931,30 +931,31 @@ class IwpFrontFn(torch.autograd.Function):
     the value and their gradient is exactly zero (returned as such so that they stay "live" for AdamW's decay)."""
 
     @staticmethod
-    def forward(ctx, x, hf_weight, hf_bias):
+    def forward(ctx, x, hf_weight, hf_bias, ct=None):
         lib = _lib.load()
         x = _f32c(x, "x")
         B, C, H, W = x.shape
-        out = torch.empty(B, C + 1, H // 2, W // 2, device=x.device, dtype=torch.float32)
-        _lib.check(_call(("iwp_front_fwd", (B, C, H, W)), lib.kmu_iwp_front_fwd, _ptr(x), _ptr(out), B, C, H, W, _stream()),
+        ct = C + 1 if ct is None else int(ct)            # > C+1: zero channels appended (channel padding for pwconv)
+        out = torch.empty(B, ct, H // 2, W // 2, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("iwp_front_fwd", (B, C, H, W)), lib.kmu_iwp_front_fwd, _ptr(x), _ptr(out), B, C, ct, H, W, _stream()),
                    "kmu_iwp_front_fwd")
-        ctx.dims = (B, C, H, W)
+        ctx.dims = (B, C, H, W, ct)
         ctx.zeros = (_const_zeros(hf_weight), None if hf_bias is None else _const_zeros(hf_bias))
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        B, C, H, W = ctx.dims
+        B, C, H, W, ct = ctx.dims
         g = _f32c(g, "grad")
         dx = torch.empty(B, C, H, W, device=g.device, dtype=torch.float32)
-        _lib.check(_call(("iwp_front_bwd", (B, C, H, W)), lib.kmu_iwp_front_bwd, _ptr(g), _ptr(dx), B, C, H, W, _stream()),
+        _lib.check(_call(("iwp_front_bwd", (B, C, H, W)), lib.kmu_iwp_front_bwd, _ptr(g), _ptr(dx), B, C, ct, H, W, _stream()),
                    "kmu_iwp_front_bwd")
-        return dx, ctx.zeros[0], ctx.zeros[1]
+        return dx, ctx.zeros[0], ctx.zeros[1], None
 
 
-def iwp_front(x, hf_weight, hf_bias):
-    return IwpFrontFn.apply(x, hf_weight, hf_bias)
+def iwp_front(x, hf_weight, hf_bias, ct=None):
+    return IwpFrontFn.apply(x, hf_weight, hf_bias, ct)
 
 
 # ------------------------------------------------------------------------------------------ squeeze-excite gates

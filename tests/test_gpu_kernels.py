@@ -403,6 +403,15 @@ def test_iwp_front_vs_slicing(B, C, H, W):
     out.backward(g.float().to(DEV))
     _report("iwp_front %s" % ((B, C, H, W),), out=rel_err(out, ref), dx=rel_err(xd.grad, x.grad))
     assert float(w.grad.abs().max()) == 0.0 and float(b.grad.abs().max()) == 0.0      # softmax over one channel
+    # channel-padded form (zero channels up to a multiple of 16, for the pointwise-conv kernels)
+    ct = (C + 1 + 15) // 16 * 16
+    xp = x.detach().float().to(DEV).requires_grad_(True)
+    outp = ops.iwp_front(xp, w.detach(), b.detach(), ct)
+    assert outp.shape[1] == ct and torch.equal(outp[:, :C + 1], out.detach()) and float(outp[:, C + 1:].abs().max()) == 0.0
+    gp = torch.randn(B, ct, H // 2, W // 2, device=DEV)
+    gp[:, :C + 1] = g.float().to(DEV)
+    outp.backward(gp)
+    assert torch.equal(xp.grad, xd.grad)
 
 
 @pytest.mark.parametrize("B,C,H,W,bias", [(2, 16, 16, 16, True), (3, 5, 7, 9, False), (8, 64, 32, 32, True)])
