@@ -407,7 +407,7 @@ def test_iwp_front_vs_slicing(B, C, H, W):
     ct = (C + 1 + 15) // 16 * 16
     xp = x.detach().float().to(DEV).requires_grad_(True)
     outp = ops.iwp_front(xp, w.detach(), b.detach(), ct)
-    assert outp.shape[1] == ct and torch.equal(outp[:, :C + 1], out.detach()) and float(outp[:, C + 1:].abs().max()) == 0.0
+    assert outp.shape[1] == ct and torch.equal(outp[:, :C + 1], out.detach()) and float(outp.detach()[:, C + 1:].abs().max()) == 0.0
     gp = torch.randn(B, ct, H // 2, W // 2, device=DEV)
     gp[:, :C + 1] = g.float().to(DEV)
     outp.backward(gp)
