@@ -225,6 +225,81 @@ __global__ __launch_bounds__(256) void dysample_bwd_tiled_kernel(const float* __
     }
 }
 
+// Channel-major variant for cg = C/4 = 16 (KM-UNet: C = 64): lane = (channel c = tid & 15, pixel slot = tid >> 4).  The 64
+// lanes of a wave then scatter into 16 different channel planes of the LDS window (plane stride 401 words => the 16
+// lanes of a DPP row hit 16 distinct banks) instead of 64 neighbouring pixels of ONE plane, whose 2x-upsampling footprints
+// collide on the same few addresses and serialise the ds_add_f32; the per-pixel offset gradient (a sum over the group's
+// channels) is a 16-lane row reduction.  Same arithmetic per (pixel, channel) as the tiled kernel above.
+constexpr int BWS = BWIN * BWIN + 1;   // 401
+
+__global__ __launch_bounds__(256) void dysample_bwd_chan_kernel(const float* __restrict__ x, const float* __restrict__ conv_out,
+                                                                const float* __restrict__ init_pos, const float* __restrict__ dy,
+                                                                float* __restrict__ dx, float* __restrict__ d_conv_out, int C, int H,
+                                                                int W, int tilesX) {
+    extern __shared__ __attribute__((aligned(16))) float win[];  // [16][BWS]
+    const int OH = 2 * H, OW = 2 * W;
+    constexpr int cg = 16;
+    const int b = blockIdx.z, g = blockIdx.y;
+    const int oy0 = (blockIdx.x / tilesX) * BT, ox0 = (blockIdx.x % tilesX) * BT;
+    const int wy0 = oy0 / 2 - 2, wx0 = ox0 / 2 - 2;
+    for (int e = threadIdx.x; e < cg * BWS; e += 256) win[e] = 0.f;
+    __syncthreads();
+    const size_t hw = (size_t)H * W;
+    const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const size_t cbase = ((size_t)b * C + (size_t)g * cg + c) * hw;
+    const float* xc = x + cbase;
+    float* dxc = dx + cbase;
+    float* wc = win + c * BWS;
+    const float* dyc = dy + ((size_t)b * C + (size_t)g * cg + c) * OH * OW;
+    for (int it = 0; it < BT * BT / 16; ++it) {
+        const int p = it * 16 + slot, oy = oy0 + p / BT, ox = ox0 + p % BT;
+        const bool live = oy < OH && ox < OW;
+        float gpx = 0.f, gpy = 0.f;
+        Samp s;
+        if (live) {
+            s = dys_coords(conv_out, init_pos, b, g, oy, ox, H, W);
+            const float w00 = (1.f - s.fx) * (1.f - s.fy), w01 = s.fx * (1.f - s.fy), w10 = (1.f - s.fx) * s.fy, w11 = s.fx * s.fy;
+            const int o00 = s.y0 * W + s.x0, o01 = s.y0 * W + s.x1, o10 = s.y1 * W + s.x0, o11 = s.y1 * W + s.x1;
+            const float go = dyc[(size_t)oy * OW + ox];
+            const float v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
+            if (s.y0 >= wy0 && s.y1 < wy0 + BWIN && s.x0 >= wx0 && s.x1 < wx0 + BWIN) {
+                const int ly0 = (s.y0 - wy0) * BWIN, ly1 = (s.y1 - wy0) * BWIN, lx0 = s.x0 - wx0, lx1 = s.x1 - wx0;
+                atomicAdd(wc + ly0 + lx0, go * w00);
+                atomicAdd(wc + ly0 + lx1, go * w01);
+                atomicAdd(wc + ly1 + lx0, go * w10);
+                atomicAdd(wc + ly1 + lx1, go * w11);
+            } else {
+                atomicAdd(dxc + o00, go * w00);
+                atomicAdd(dxc + o01, go * w01);
+                atomicAdd(dxc + o10, go * w10);
+                atomicAdd(dxc + o11, go * w11);
+            }
+            gpx = go * ((v01 - v00) * (1.f - s.fy) + (v11 - v10) * s.fy);
+            gpy = go * ((v10 - v00) * (1.f - s.fx) + (v11 - v01) * s.fx);
+        }
+        // sum over the 16 channel lanes of this pixel (one DPP row): row_shr 1, 2, 4, 8 leaves the total in lane 15
+        gpx += kmu::dpp_mov<0x111, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x111, 0xf>(0.f, gpy);
+        gpx += kmu::dpp_mov<0x112, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x112, 0xf>(0.f, gpy);
+        gpx += kmu::dpp_mov<0x114, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x114, 0xf>(0.f, gpy);
+        gpx += kmu::dpp_mov<0x118, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x118, 0xf>(0.f, gpy);
+        if (live && c == 15) {
+            const int h = oy >> 1, i = oy & 1, w = ox >> 1, j = ox & 1;
+            const int chx = g * 4 + i * 2 + j, chy = 16 + chx;
+            const size_t pix = (size_t)h * W + w;
+            d_conv_out[((size_t)b * 32 + chx) * hw + pix] = s.in_x ? 0.25f * gpx : 0.f;
+            d_conv_out[((size_t)b * 32 + chy) * hw + pix] = s.in_y ? 0.25f * gpy : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cg * BWIN * BWIN; e += 256) {
+        const int cc = e / (BWIN * BWIN), r = e % (BWIN * BWIN);
+        const float v = win[cc * BWS + r];
+        if (v == 0.f) continue;
+        const int yy = wy0 + r / BWIN, xx = wx0 + r % BWIN;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(dx + ((size_t)b * C + (size_t)g * cg + cc) * hw + (size_t)yy * W + xx, v);
+    }
+}
+
 int grid_for(size_t total) {
     size_t blocks = (total + 255) / 256;
     return (int)(blocks > 8192 ? 8192 : (blocks ? blocks : 1));
@@ -248,6 +323,12 @@ extern "C" int kmu_dysample_lp_bwd(const float* x, const float* conv_out, const 
     KMU_REQUIRE(x && conv_out && init_pos && dy && dx && d_conv_out, "dysample_lp_bwd: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "dysample_lp_bwd: bad dims");
     const size_t lds = (size_t)(C / 4) * BWIN * BWIN * sizeof(float);
+    if (C == 64 && B <= 65535) {
+        const int tilesX = kmu::cdiv(2 * W, BT), tilesY = kmu::cdiv(2 * H, BT);
+        hipLaunchKernelGGL(dysample_bwd_chan_kernel, dim3(tilesX * tilesY, 4, B), dim3(256), (size_t)16 * BWS * sizeof(float),
+                           (hipStream_t)stream, x, conv_out, init_pos, dy, dx, d_conv_out, C, H, W, tilesX);
+        return kmu::launch_status("dysample_lp_bwd");
+    }
     if (lds <= 64 * 1024 && B <= 65535) {
         const int tilesX = kmu::cdiv(2 * W, BT), tilesY = kmu::cdiv(2 * H, BT);
         KMU_MAX_LDS(dysample_bwd_tiled_kernel, lds);
