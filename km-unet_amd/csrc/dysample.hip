@@ -230,29 +230,30 @@ __global__ __launch_bounds__(256) void dysample_bwd_tiled_kernel(const float* __
 // lanes of a DPP row hit 16 distinct banks) instead of 64 neighbouring pixels of ONE plane, whose 2x-upsampling footprints
 // collide on the same few addresses and serialise the ds_add_f32; the per-pixel offset gradient (a sum over the group's
 // channels) is a 16-lane row reduction.  Same arithmetic per (pixel, channel) as the tiled kernel above.
-constexpr int BWS = BWIN * BWIN + 1;   // 401
 
+template <int TB>   // output tile edge: 32 (window 20x20) or 16 (window 12x12: 4x the workgroups, for the small levels)
 __global__ __launch_bounds__(256) void dysample_bwd_chan_kernel(const float* __restrict__ x, const float* __restrict__ conv_out,
                                                                 const float* __restrict__ init_pos, const float* __restrict__ dy,
                                                                 float* __restrict__ dx, float* __restrict__ d_conv_out, int C, int H,
                                                                 int W, int tilesX) {
-    extern __shared__ __attribute__((aligned(16))) float win[];  // [16][BWS]
+    constexpr int WN = TB / 2 + 4, WS = WN * WN + 1;   // window edge; plane stride (odd => the 16 channel lanes hit 16 banks)
+    extern __shared__ __attribute__((aligned(16))) float win[];  // [16][WS]
     const int OH = 2 * H, OW = 2 * W;
     constexpr int cg = 16;
     const int b = blockIdx.z, g = blockIdx.y;
-    const int oy0 = (blockIdx.x / tilesX) * BT, ox0 = (blockIdx.x % tilesX) * BT;
+    const int oy0 = (blockIdx.x / tilesX) * TB, ox0 = (blockIdx.x % tilesX) * TB;
     const int wy0 = oy0 / 2 - 2, wx0 = ox0 / 2 - 2;
-    for (int e = threadIdx.x; e < cg * BWS; e += 256) win[e] = 0.f;
+    for (int e = threadIdx.x; e < cg * WS; e += 256) win[e] = 0.f;
     __syncthreads();
     const size_t hw = (size_t)H * W;
     const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
     const size_t cbase = ((size_t)b * C + (size_t)g * cg + c) * hw;
     const float* xc = x + cbase;
     float* dxc = dx + cbase;
-    float* wc = win + c * BWS;
+    float* wc = win + c * WS;
     const float* dyc = dy + ((size_t)b * C + (size_t)g * cg + c) * OH * OW;
-    for (int it = 0; it < BT * BT / 16; ++it) {
-        const int p = it * 16 + slot, oy = oy0 + p / BT, ox = ox0 + p % BT;
+    for (int it = 0; it < TB * TB / 16; ++it) {
+        const int p = it * 16 + slot, oy = oy0 + p / TB, ox = ox0 + p % TB;
         const bool live = oy < OH && ox < OW;
         float gpx = 0.f, gpy = 0.f;
         Samp s;
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(256) void dysample_bwd_chan_kernel(const float* __r
             const int o00 = s.y0 * W + s.x0, o01 = s.y0 * W + s.x1, o10 = s.y1 * W + s.x0, o11 = s.y1 * W + s.x1;
             const float go = dyc[(size_t)oy * OW + ox];
             const float v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
-            if (s.y0 >= wy0 && s.y1 < wy0 + BWIN && s.x0 >= wx0 && s.x1 < wx0 + BWIN) {
-                const int ly0 = (s.y0 - wy0) * BWIN, ly1 = (s.y1 - wy0) * BWIN, lx0 = s.x0 - wx0, lx1 = s.x1 - wx0;
+            if (s.y0 >= wy0 && s.y1 < wy0 + WN && s.x0 >= wx0 && s.x1 < wx0 + WN) {
+                const int ly0 = (s.y0 - wy0) * WN, ly1 = (s.y1 - wy0) * WN, lx0 = s.x0 - wx0, lx1 = s.x1 - wx0;
                 atomicAdd(wc + ly0 + lx0, go * w00);
                 atomicAdd(wc + ly0 + lx1, go * w01);
                 atomicAdd(wc + ly1 + lx0, go * w10);
@@ -291,11 +292,11 @@ __global__ __launch_bounds__(256) void dysample_bwd_chan_kernel(const float* __r
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < cg * BWIN * BWIN; e += 256) {
-        const int cc = e / (BWIN * BWIN), r = e % (BWIN * BWIN);
-        const float v = win[cc * BWS + r];
+    for (int e = threadIdx.x; e < cg * WN * WN; e += 256) {
+        const int cc = e / (WN * WN), r = e % (WN * WN);
+        const float v = win[cc * WS + r];
         if (v == 0.f) continue;
-        const int yy = wy0 + r / BWIN, xx = wx0 + r % BWIN;
+        const int yy = wy0 + r / WN, xx = wx0 + r % WN;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(dx + ((size_t)b * C + (size_t)g * cg + cc) * hw + (size_t)yy * W + xx, v);
     }
 }
@@ -324,9 +325,14 @@ extern "C" int kmu_dysample_lp_bwd(const float* x, const float* conv_out, const 
     KMU_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "dysample_lp_bwd: bad dims");
     const size_t lds = (size_t)(C / 4) * BWIN * BWIN * sizeof(float);
     if (C == 64 && B <= 65535) {
-        const int tilesX = kmu::cdiv(2 * W, BT), tilesY = kmu::cdiv(2 * H, BT);
-        hipLaunchKernelGGL(dysample_bwd_chan_kernel, dim3(tilesX * tilesY, 4, B), dim3(256), (size_t)16 * BWS * sizeof(float),
-                           (hipStream_t)stream, x, conv_out, init_pos, dy, dx, d_conv_out, C, H, W, tilesX);
+        // 16x16 output tiles (12x12 input window): the per-workgroup loop is a serial chain of gathers and LDS atomics, so
+        // more, shorter workgroups win at every level -- measured (B=8) against 32x32 tiles: 16x16 input 94 -> 28 us,
+        // 32x32 94 -> 53 us, 64x64 183 -> 177 us
+        constexpr int tb = 16;
+        const int tilesX = kmu::cdiv(2 * W, tb), tilesY = kmu::cdiv(2 * H, tb);
+        const size_t ldsc = (size_t)16 * ((tb / 2 + 4) * (tb / 2 + 4) + 1) * sizeof(float);
+        hipLaunchKernelGGL(dysample_bwd_chan_kernel<tb>, dim3(tilesX * tilesY, 4, B), dim3(256), ldsc, (hipStream_t)stream, x, conv_out,
+                           init_pos, dy, dx, d_conv_out, C, H, W, tilesX);
         return kmu::launch_status("dysample_lp_bwd");
     }
     if (lds <= 64 * 1024 && B <= 65535) {
