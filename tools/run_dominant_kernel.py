@@ -24,3 +24,19 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     ops.kan_conv2d(xk, grid, *kw)
 torch.cuda.synchronize()
 print("done")
+
+# ---- streaming glue kernels at the bench shapes (for the FETCH_SIZE / WRITE_SIZE passes) --------------------------
+import torch.nn as nn
+xg = torch.randn(B, 16, 128, 128, device=d, requires_grad=True)
+w1 = torch.randn(64, 16, 1, 1, device=d, requires_grad=True)
+wdw = torch.randn(16, 1, 3, 3, device=d, requires_grad=True)
+bn = nn.BatchNorm2d(16).to(d).train()
+alpha = torch.zeros(16, device=d, requires_grad=True)
+g64 = torch.randn(B, 64, 128, 128, device=d)
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    y = ops.pwconv(xg, w1, None)                    # 16 -> 64 @ 128x128: fwd, dgrad, wgrad
+    y.backward(g64)
+    z = ops.dw_bn_blend(xg, type("C", (), {"weight": wdw})(), bn, alpha)   # dwconv3x3 + BN(train) + blend: fwd / bwd
+    z.backward(gy)
+torch.cuda.synchronize()
+print("glue done")
