@@ -14,8 +14,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the dominant hand-written kernel of the step, timed per launch with HIP events on the
                   launch stream during extra instrumented steps of the same workload;
   cpu_baseline -- the CPU oracle ("port" of the reference op sequence) timed on this host's cores
-                  on a bounded sample (B=2, same T/H/W), N=1 only;
-  kernels      -- per-entry-point totals of those instrumented steps (ms per step).
+                  at the headline configuration (B=8, same T/H/W; 1 warm-up + 2 timed steps), N=1 only.
+The printed line stays under 2 KB (the driver keeps only a short tail of stdout); the per-entry-point table of the
+instrumented steps (ms per step, GB/s, TFLOP/s for ~200 (kernel, shape) pairs) goes to --kernels-out
+(default gpurun_out/bench_kernels.json) and its top rows to stderr.
 """
 import argparse
 import json
@@ -123,8 +125,8 @@ def _kernel_model(name, shape):
     return "hbm", 0.0, 0.0
 
 
-def cpu_baseline(T, H, steps=3, loss="hybrid"):
-    """CPU oracle (oracle/model.py = the reference's op sequence) fwd + loss + bwd + AdamW, B=2."""
+def cpu_baseline(T, H, B=8, steps=2, loss="hybrid"):
+    """CPU oracle (oracle/model.py = the reference's op sequence) fwd + loss + bwd + AdamW at the headline batch."""
     from oracle.loss import hybrid_loss
     from oracle.model import KM_UNetV3 as Oracle
     crit = hybrid_loss if loss == "hybrid" else torch.nn.functional.mse_loss
@@ -132,7 +134,6 @@ def cpu_baseline(T, H, steps=3, loss="hybrid"):
     # one GPU's host share on the box is 16 cores; more threads only add oversubscription on these
     # small tensors (measured: 128 threads = 14.6 s/step, slower than 8 threads in the build container)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    B = 2
     m = Oracle(num_classes=T - 5).train()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.05)
     data = torch.rand(B, T, 1, H, H)
@@ -164,14 +165,23 @@ def main():
     ap.add_argument("--loss", choices=("hybrid", "mse"), default="hybrid",
                     help="hybrid = the reference's HybridLoss (train_shanghai.py:298-325), the default; mse = plain MSE")
     ap.add_argument("--no-graph", action="store_true", help="run eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--kernels-out", default=os.path.join(ROOT, "gpurun_out", "bench_kernels.json"),
+                    help="where the per-entry-point table of the instrumented steps is written (not on stdout)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (children of a parent that never touched the
+        # GPU -- no exec from a HIP-initialised process) and relay rank 0's line
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # KMU_DIST_BACKEND=gloo lets the N>1 code path be rehearsed with several ranks sharing one GPU
     # (RCCL refuses two ranks on one device); the real runs use "nccl" (= RCCL over xGMI).
     backend = os.environ.get("KMU_DIST_BACKEND", "nccl")
@@ -263,17 +273,32 @@ def main():
             roof = {"bound": "hbm", "achieved": d["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["GB/s"] / PEAK_HBM_GBS}
         roof.update({"traffic": pmc_traffic(name, shape), "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_flops": flops,
                      "algorithmic_bytes": byts, "hbm_GBps_on_algorithmic_bytes": d["GB/s"]})
-        out["roofline"] = roof
-        out["kernels"] = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
-                          sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}
-        out["hip_kernels_ms_per_step"] = sum(v["ms_per_step"] for v in table.values())
+        out["roofline"] = {k: (float("%.5g" % v) if isinstance(v, float) else v) for k, v in roof.items()}
+        out["hip_kernels_ms_per_step"] = round(sum(v["ms_per_step"] for v in table.values()), 4)
+        kernels = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
+                   sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        try:
+            os.makedirs(os.path.dirname(args.kernels_out), exist_ok=True)
+            with open(args.kernels_out, "w") as f:
+                json.dump({"config": out["config"], "ms_per_step": ms, "kernels": kernels}, f, indent=1)
+            out["kernels_table"] = os.path.relpath(args.kernels_out, ROOT)
+        except OSError as e:                          # read-only checkout: the table is a convenience, not the contract
+            out["kernels_table"] = "not written (%s)" % e
+        for k, v in list(kernels.items())[:12]:
+            print("bench: %-52s %6.3f ms/step  %5.1f launches  %s" % (k, v["ms_per_step"], v["launches_per_step"], v["bound"]),
+                  file=sys.stderr)
 
     if world > 1:
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, H, loss=args.loss)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(T, H, B=B, loss=args.loss)
+        for k in ("value", "ms_per_step", "loss_first", "loss"):
+            out[k] = float("%.6g" % out[k])
+        line = json.dumps(out)
+        assert len(line) < 2048, "bench line too long for the driver's stdout tail: %d" % len(line)
+        sys.stderr.flush()
+        print(line, flush=True)                       # the contract line: last thing on stdout
     if world > 1:
         dist.destroy_process_group()
 

@@ -12,13 +12,22 @@ import os as _os
 #  * MIOPEN_DEBUG_CONV_WINOGRAD=0 -- precaution for fp32 parity: fp32 Winograd transforms carry a larger rounding error
 #    than direct / implicit-GEMM convolution and whether MIOpen picks them depends on a timing-based search, i.e. on the
 #    box.  None of the glue convolutions in profiles/ ran on a Winograd kernel, so nothing is lost.
-#  * DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 -- the HIP runtime's AQL packet capture for graphs (default on in ROCm 7) replays
-#    the multi-thousand-node train-step graph wrongly once the host has synchronised the stream between two replays:
-#    reductions inside the captured loss return garbage from then on (measured on MI355X,
-#    tools/repro_graph_replay_sync.py: 0.4332 -> 216.4; correct with the capture path off, six other runtime knobs
-#    made no difference, profiles/r01c_graph_replay_runtime_knobs.log).  No cost in step time.
+#  * DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 -- precaution, not a dependency.  Round 1 saw hipGraph replays of the train step
+#    return garbage from the third replay on (loss 0.43 -> 216) with the runtime's AQL packet capture (default on in
+#    ROCm 7).  Bisected in round 2 (tools/graph_replay_bisect.py, profiles/r02_graph_replay_bisect.log): the step built
+#    from this library's kernels, including the fused HybridLoss, replays correctly WITH packet capture on in every
+#    configuration tried; the failure needs the tensor-op HybridLoss fallback (ATen reductions / reflect pad / cat) plus
+#    DropPath's captured bernoulli_ in the same graph.  That fallback now refuses to be captured with packet capture on
+#    (loss.py), and GraphedTrainStep validates every captured graph against an eager step before handing it out
+#    (train.py).  The default below only matters for callers that import this package before the first HIP call.
+import torch as _torch
+
+# True when the HIP runtime was already up (so it has read its flags) without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: the default
+# set below then comes too late, and loss.py's capture guard must treat packet capture as ON.
+PACKET_CAPTURE_MAY_BE_ON = _torch.cuda.is_initialized() and _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0"
 _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+if not PACKET_CAPTURE_MAY_BE_ON:
+    _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 from . import _lib, ops  # noqa: E402,F401
 from .model import KM_UNetV3  # noqa: E402,F401

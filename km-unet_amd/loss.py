@@ -50,6 +50,7 @@ class HybridLoss(nn.Module):
         if pred.is_cuda and self.k == 11 and min(pred.shape[-2:]) >= 12 and not target.requires_grad:
             from . import ops
             return ops.hybrid_loss(pred, target, self.gauss, self.alpha)      # fused: 6 launches forward, 3 backward
+        _refuse_unsafe_capture(pred)
         d = pred - target
         sq = d * d
         mse = sq.mean()
@@ -59,6 +60,20 @@ class HybridLoss(nn.Module):
         tn = (target - tmin) / (tmax - tmin + 1e-8)
         pn = (pred - pmin) / (pmax - pmin + 1e-8)
         return self.alpha * (0.55 * mse + 0.45 * weighted) + (1 - self.alpha) * (1 - self.ssim(pn, tn))
+
+
+def _refuse_unsafe_capture(t):
+    """The tensor-op formulation above, captured into a hipGraph together with DropPath's bernoulli_, is the ONE program
+    whose replays went wrong on ROCm 7.2 with the runtime's AQL packet capture enabled (third replay onwards: loss 0.43 ->
+    216; tools/graph_replay_bisect.py --loss aten).  The fused kernels (ops.hybrid_loss) replay
+    correctly with or without it.  Capturing this path with packet capture on is therefore refused instead of risked."""
+    import os
+    from . import PACKET_CAPTURE_MAY_BE_ON
+    on = PACKET_CAPTURE_MAY_BE_ON or os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0"
+    if on and t.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("HybridLoss: the tensor-op fallback must not be captured into a hipGraph while the HIP runtime's graph "
+                           "packet capture is enabled (set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first HIP call, or use the "
+                           "fused path: CUDA tensors, 11-tap window, images >= 12x12, target without requires_grad)")
 
 
 THRESHOLDS = (20, 30, 35, 40)

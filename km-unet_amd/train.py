@@ -51,9 +51,16 @@ class GraphedTrainStep:
     otherwise make the loop host-bound.  One process: a single graph holds zero-grad, forward, loss, backward
     and the fused AdamW.  Several processes: graph 1 = zero-grad + forward + backward, then the (eager) RCCL
     all-reduce of the flat gradient bucket, then graph 2 = AdamW -- the collective stays outside the capture.
-    Requires TrainStep(..., capturable=True); shapes are static; DropPath draws from the captured Philox stream."""
+    Requires TrainStep(..., capturable=True); shapes are static; DropPath draws from the captured Philox stream.
 
-    def __init__(self, step, example_data, warmup=3):
+    Self-check (`validate=True`, the default): before it is handed out, the captured step is replayed three times with
+    a host synchronisation between replays and each loss is compared with ONE eager step from the same weights,
+    optimizer state and buffers (restored afterwards, so construction leaves the training state where it found it).
+    Round 1 met a runtime whose graph replays returned garbage from the third replay on (loss 0.43 -> 216, see
+    DESIGN.md section 5); a graph that does not reproduce the eager step raises here instead of training on noise.
+    `check_loss()` repeats the cheap part (finite, no jump against the previous call) at any later point."""
+
+    def __init__(self, step, example_data, warmup=3, validate=True):
         self.step = step
         self.static_data = example_data.clone()
         side = torch.cuda.Stream()
@@ -63,6 +70,7 @@ class GraphedTrainStep:
                 step(self.static_data)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        snap = self._snapshot() if validate else None
         self.g1 = torch.cuda.CUDAGraph()
         self.g2 = None
         if step.dp.world == 1:
@@ -74,6 +82,55 @@ class GraphedTrainStep:
             self.g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g2):
                 step.opt.step()
+        self._last = None
+        if validate:
+            self._validate(snap)
+
+    # ---- state that one step changes: parameters (flat), AdamW moments + step counter, module buffers (BatchNorm) ----
+    def _state_tensors(self):
+        ts = [self.step.flat_param.data, self.step.dp.bucket.flat]
+        for st in self.step.opt.state.values():
+            ts += [v for v in st.values() if torch.is_tensor(v)]
+        ts += [b for b in self.step.model.buffers()]
+        return ts
+
+    def _snapshot(self):
+        return [t.detach().clone() for t in self._state_tensors()], torch.cuda.get_rng_state()
+
+    def _restore(self, snap):
+        with torch.no_grad():
+            for t, s in zip(self._state_tensors(), snap[0]):
+                t.copy_(s)
+        torch.cuda.set_rng_state(snap[1])
+
+    def _validate(self, snap):
+        self._restore(snap)
+        ref = float(self.step(self.static_data))                 # eager step from the snapshot
+        # DropPath masks of a replay need not equal the eager step's (different Philox offsets): its per-sample
+        # Bernoulli(0.9) scaling moves the loss by a few per cent at most, garbage moves it by orders of magnitude
+        tol = 0.25 * abs(ref) + 1e-3
+        self._restore(snap)
+        seen = []
+        for i in range(3):
+            torch.cuda.current_stream().synchronize()
+            seen.append(float(self(self.static_data)))
+            if i == 0 and not (abs(seen[0] - ref) <= tol):
+                break
+        ok = all(v == v and abs(v - ref) <= tol for v in seen)
+        self._restore(snap)
+        self._last = None
+        if not ok:
+            raise RuntimeError("GraphedTrainStep: the captured step does not reproduce the eager step (eager loss %.6g, replays %s). "
+                               "Run eagerly (TrainStep) or see DESIGN.md section 5 (DEBUG_CLR_GRAPH_PACKET_CAPTURE)." % (ref, seen))
+
+    def check_loss(self, factor=4.0):
+        """Host-side sanity check of the last replay's loss (one device sync): finite, and not `factor` times the loss at
+        the previous check.  Cheap enough for every logging interval of a training loop."""
+        v = float(self.loss)
+        if not (v == v) or v in (float("inf"), float("-inf")) or (self._last is not None and v > factor * self._last + 1e-3):
+            raise RuntimeError("GraphedTrainStep: loss %.6g after %.6g -- the replayed graph no longer computes the step" % (v, self._last or float("nan")))
+        self._last = v
+        return v
 
     def __call__(self, data):
         if data is not self.static_data:

@@ -61,12 +61,27 @@ def test_whole_model_golden(name, variant, nc, train):
     assert e_y < TOL and abs(loss.item() - g["loss"].item()) < 1e-6
     if not train:
         assert e_dx < TOL and o_dx < 1e-4 and worst[1] < TOL and bad == 0
-    else:
-        # Train mode: BatchNorm's batch-statistic backward couples every element of a channel, so the few
-        # activations that take the other ReLU / floor() branch (see module docstring) are no longer local: they
-        # shift whole-channel gradients by O(1e-3).  The train-mode machinery itself is pinned at ~1e-6 by the
-        # block-level fixtures (evim_train, bn_blend train cases, K2 backward); here only a gross bound applies.
-        assert e_dx < 1e-2 and o_dx < 2e-2 and worst[1] < 1e-2
+        return
+    # Train mode.  The fixture is the reference's own output; the HIP model has to match it in EVERY gradient tensor
+    # (input + parameters, max-norm relative to the tensor's largest entry) to 2e-3 -- either directly or after the
+    # ReLU-tie allowance of oracle/ties.py: the residual must be a {0,1}-combination of single-element branch flips at
+    # pre-activations the fp64 oracle puts within 3e-6 of zero (relative to the layer maximum).  Why 2e-3 and not
+    # 1e-3: BatchNorm's batch-statistic backward divides by per-channel standard deviations of ~1e-2 at this size, and
+    # the fixture itself (fp32 reference) sits ~3e-4 from the fp64 oracle on the smallest parameter tensors.
+    if e_dx < TOL and o_dx < 1e-4 and worst[1] < TOL:
+        return
+    from oracle import ties
+    from oracle.model import KM_UNetV3 as Oracle, fill_parameters
+    o64 = fill_parameters(Oracle(num_classes=nc, variant=variant), 1).train().double()
+    for sub in o64.modules():
+        if hasattr(sub, "drop_prob"):
+            sub.drop_prob = 0.0
+    tgt = g["target"].double()
+    got = {"<input>": x.grad.cpu()}
+    got.update({k: v.cpu() for k, v in grads.items()})
+    ok, rep = ties.explain_by_ties(o64, g["x"].double(), lambda out: torch.nn.functional.mse_loss(out, tgt), got, tol=2e-3)
+    print("  [%s] tie analysis: %s" % (name, ties.describe(rep)))
+    assert ok, ties.describe(rep)
 
 
 def test_model_matches_oracle_at_128():
