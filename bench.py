@@ -188,7 +188,10 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # KMU_FORCE_DIST=1: take the distributed code path (process group, two-graph step, eager all-reduce between the graphs)
+    # with a single rank too, so that the RCCL path runs on a one-GPU box (tests/test_gpu_model.py)
+    force_dist = os.environ.get("KMU_FORCE_DIST", "0") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -205,12 +208,12 @@ def main():
     model = km_unet_amd.KM_UNetV3(num_classes=T - 5).to(dev).train()
     torch.manual_seed(1234 + rank)            # per-rank data shard and DropPath stream
     data = torch.rand(B, T, 1, H, H, device=dev)
-    eager = TrainStep(model, data, capturable=not args.no_graph, loss=args.loss)
+    eager = TrainStep(model, data, capturable=not args.no_graph, loss=args.loss, force_collective=force_dist)
     step = eager if args.no_graph else GraphedTrainStep(eager, data)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -225,7 +228,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     final_loss = loss.item()
@@ -244,7 +247,8 @@ def main():
                "config": {"workload": "KM_UNetV3_SH(num_classes=%d) train step (fwd + %s loss + bwd + grad all-reduce + AdamW), "
                                       "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, args.loss, B, T, H, H),
                           "global_batch": world * B, "frames_per_sample": T, "parallelism": "dp%d" % world},
-               "loss_first": loss_ref, "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay"}
+               "loss_first": loss_ref, "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay",
+               "collective": ("%s all-reduce of %d floats per step" % (backend, eager.dp.bucket.numel())) if eager.dp.collective else "none (1 rank)"}
 
     # ---- roofline leg: extra instrumented steps, HIP events around every C-ABI launch ----------
     # (every rank runs them -- a step contains the gradient all-reduce -- only rank 0 records and reports)
@@ -288,7 +292,7 @@ def main():
             print("bench: %-52s %6.3f ms/step  %5.1f launches  %s" % (k, v["ms_per_step"], v["launches_per_step"], v["bound"]),
                   file=sys.stderr)
 
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -299,7 +303,7 @@ def main():
         assert len(line) < 2048, "bench line too long for the driver's stdout tail: %d" % len(line)
         sys.stderr.flush()
         print(line, flush=True)                       # the contract line: last thing on stdout
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -343,6 +343,15 @@ int kmu_group_norm_bwd(const float* x, const float* gout, const float* gamma, co
                        float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW,
                        kmu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Contingency counts of the reference evaluator (metrics.py:45-47 float2int: clip(x,0,1)*scale as uint16; :105-114
+ * _cal_frame; :220-288 pools TP/FN/FP/TN over all frames before forming CSI / POD / FAR / HSS): one pass over
+ * pred / target [n] (16-byte aligned), counts [n_thresholds][3] = {TP, FN, FP} as 64-bit integers ADDED to the
+ * caller-zeroed buffer (integer atomics: exact and deterministic); TN = n - TP - FN - FP.  thresholds: HOST array.
+ * ------------------------------------------------------------------------------------ */
+int kmu_contingency_counts(const float* pred, const float* target, unsigned long long* counts, size_t n,
+                           const int* thresholds, int n_thresholds, float scale, kmu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,7 @@ SIGNATURES = {
     "kmu_pwconv_bwd_input_add": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_partials": (_I, [_I]),
     "kmu_dwconv3x3_bwd_weight": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 
 _lock = threading.Lock()

@@ -34,6 +34,7 @@ SOURCES = [
     ("mix3.hip", []),
     ("shift3.hip", []),
     ("hybrid_loss.hip", []),
+    ("contingency.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -81,10 +81,13 @@ def live_parameters(model, example_input, loss_fn=None):
 class DataParallel:
     """Minimal DDP: broadcast parameters/buffers from rank 0, average gradients after backward."""
 
-    def __init__(self, model, live_params, process_group=None):
+    def __init__(self, model, live_params, process_group=None, force_collective=False):
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collective: run the all-reduce (and the two-graph step split around it) even with a single rank -- lets the
+        # RCCL code path execute on a one-GPU box (RCCL accepts a 1-rank communicator)
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         if self.world > 1:
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
@@ -102,7 +105,7 @@ class DataParallel:
         self.bucket.store(torch.autograd.grad(loss, self.bucket.params))
 
     def all_reduce_grads(self):
-        if self.world == 1:
+        if not self.collective:
             return
         dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
         self.bucket.flat.div_(self.world)

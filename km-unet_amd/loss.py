@@ -79,19 +79,42 @@ def _refuse_unsafe_capture(t):
 THRESHOLDS = (20, 30, 35, 40)
 
 
-def contingency_scores(pred, target, thresholds=THRESHOLDS, scale=90):
-    """-> {threshold: {csi, pod, far, hss}} from pooled TP/FN/FP/TN counts, computed on the device; the uint16
-    truncation of clip(x,0,1)*scale is the reference's (metrics.py:45-47)."""
-    p = (pred.detach().clamp(0, 1) * scale).to(torch.int32)
-    t = (target.detach().clamp(0, 1) * scale).to(torch.int32)
+def contingency_counts(pred, target, thresholds=THRESHOLDS, scale=90):
+    """-> int64 tensor [len(thresholds), 4] = (TP, FN, FP, TN) pooled over every element, on the inputs' device.
+    CUDA tensors: ONE HIP reduction (csrc/contingency.hip) and no host synchronisation; the uint16 truncation of
+    clip(x,0,1)*scale is the reference's (metrics.py:45-47).  CPU tensors: the same counts with tensor ops."""
+    n = pred.numel()
+    if pred.is_cuda:
+        import ctypes
+        from . import _lib, ops
+        p = ops._f32c(pred.detach(), "pred").reshape(-1)
+        t = ops._f32c(target.detach(), "target").reshape(-1)
+        k = len(thresholds)
+        counts = torch.zeros(k, 3, device=p.device, dtype=torch.int64)
+        th = (ctypes.c_int * k)(*[int(v) for v in thresholds])
+        _lib.check(_lib.load().kmu_contingency_counts(p.data_ptr(), t.data_ptr(), counts.data_ptr(), n, th, k, float(scale),
+                                                      ops._stream()), "kmu_contingency_counts")
+    else:
+        pi = (pred.detach().float().clamp(0, 1) * scale).to(torch.int32).reshape(1, -1)
+        ti = (target.detach().float().clamp(0, 1) * scale).to(torch.int32).reshape(1, -1)
+        th = torch.tensor(list(thresholds), dtype=torch.int32).view(-1, 1)
+        pb, tb = pi >= th, ti >= th
+        counts = torch.stack(((pb & tb).sum(1), (~pb & tb).sum(1), (pb & ~tb).sum(1)), dim=1)
+    return torch.cat((counts, n - counts.sum(1, keepdim=True)), dim=1)
+
+
+def scores_from_counts(counts, thresholds=THRESHOLDS):
+    """{threshold: {csi, pod, far, hss}} from a [T,4] (TP, FN, FP, TN) count table (metrics.py:258-264; the reference divides
+    unguarded, a zero denominator gives nan).  One device-to-host copy when `counts` lives on the GPU."""
     out = {}
-    for th in thresholds:
-        pb, tb = p >= th, t >= th
-        tp = (pb & tb).sum().item()
-        fn = (~pb & tb).sum().item()
-        fp = (pb & ~tb).sum().item()
-        tn = (~pb & ~tb).sum().item()
-        div = lambda a, b: float(a) / b if b else float("nan")
+    div = lambda a, b: float(a) / b if b else float("nan")
+    for th, (tp, fn, fp, tn) in zip(thresholds, counts.tolist()):
         out[th] = {"csi": div(tp, tp + fp + fn), "pod": div(tp, tp + fn), "far": div(fp, tp + fp),
                    "hss": div(2 * (tp * tn - fp * fn), fp ** 2 + fn ** 2 + 2 * tp * tn + (fp + fn) * (tp + tn))}
     return out
+
+
+def contingency_scores(pred, target, thresholds=THRESHOLDS, scale=90):
+    """CSI / POD / FAR / HSS per threshold: one reduction on the device + a single D2H copy of the 4x4 count table.
+    An evaluator over many batches sums contingency_counts() tables on the device and calls scores_from_counts() once."""
+    return scores_from_counts(contingency_counts(pred, target, thresholds, scale), thresholds)

@@ -4,6 +4,8 @@ backward -> optimizer step.  AdamW(lr 1e-3, weight_decay 0.05) as train_shanghai
 
 Loss: the reference's HybridLoss (train_shanghai.py:298-325; km-unet_amd/loss.py) by default, plain MSE on request.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -19,15 +21,17 @@ def split_frames(data):
 
 class TrainStep:
     def __init__(self, model, example_data, lr=1e-3, weight_decay=0.05, process_group=None, capturable=False,
-                 loss="hybrid"):
+                 loss="hybrid", force_collective=False):
         self.model = model
         self.criterion = HybridLoss().to(example_data.device) if loss == "hybrid" else F.mse_loss
         inp, _ = split_frames(example_data)
         live = live_parameters(model, inp)
-        self.dp = DataParallel(model, live, process_group)
+        self.dp = DataParallel(model, live, process_group, force_collective)
         kw = dict(lr=lr, weight_decay=weight_decay)
         if example_data.is_cuda:
             kw.update(fused=True, capturable=capturable)
+            if capturable:      # the learning rate lives in a device tensor: a schedule can change it under a captured graph
+                kw["lr"] = torch.tensor(float(lr), device=example_data.device, dtype=torch.float32)
         # one flat parameter tensor (its .grad is the flat gradient bucket): AdamW is a single launch
         self.flat_param = self.dp.bucket.flatten_parameters()
         self.opt = torch.optim.AdamW([self.flat_param], **kw)
@@ -44,6 +48,31 @@ class TrainStep:
         self.dp.all_reduce_grads()
         self.opt.step()
         return loss
+
+
+class CosineAnnealing:
+    """torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=200, eta_min=5e-4), stepped once per epoch
+    (train_shanghai.py:398-399, :415), in closed form:  eta_min + (base - eta_min) (1 + cos(pi t / T_max)) / 2.
+    When the optimizer holds its learning rate in a device tensor (TrainStep(capturable=True)) the new value is written
+    IN PLACE, so a captured hipGraph picks it up at its next replay; a float learning rate is simply replaced."""
+
+    def __init__(self, optimizer, T_max=200, eta_min=5e-4):
+        self.opt, self.T_max, self.eta_min, self.last_epoch = optimizer, T_max, eta_min, 0
+        self.base = [float(g["lr"]) for g in optimizer.param_groups]
+
+    def lr_at(self, epoch):
+        return [self.eta_min + (b - self.eta_min) * (1.0 + math.cos(math.pi * epoch / self.T_max)) / 2.0 for b in self.base]
+
+    def step(self):
+        self.last_epoch += 1
+        for g, lr in zip(self.opt.param_groups, self.lr_at(self.last_epoch)):
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+
+    def get_last_lr(self):
+        return [float(g["lr"]) for g in self.opt.param_groups]
 
 
 class GraphedTrainStep:
@@ -73,7 +102,7 @@ class GraphedTrainStep:
         snap = self._snapshot() if validate else None
         self.g1 = torch.cuda.CUDAGraph()
         self.g2 = None
-        if step.dp.world == 1:
+        if not step.dp.collective:
             with torch.cuda.graph(self.g1):
                 self.loss = step(self.static_data)
         else:

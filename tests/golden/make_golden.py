@@ -14,6 +14,7 @@ What each fixture pins (reference file:line):
   k3_*.npz     DySample_md.py:49-68 (+ integer gather indices from the oracle's
                index-explicit form after it reproduced F.grid_sample's output)
   iwp_*.npz    WPL/iwp.py:116-132
+  dagem_plain_*.npz  DAGEM_md.py:56-111 with the deformable conv replaced by a plain conv on both sides
   model_*.npz  KM_UNetV3_SH.py:465-517 / KM_UNetV3_LAPS.py (DAGEM's deform-conv
                = oracle restatement of torchvision => that sub-block is unpinned)
   manifest_*.txt  state_dict key / shape / dtype lists
@@ -167,6 +168,24 @@ def gen_iwp(ref):
     save("iwp_c16", x=x, gy=gy, y=y, dx=x.grad)
 
 
+def gen_dagem(ref):
+    """DAGEM_md.py:56-111 with the deformable conv replaced by oracle.dagem.plain_conv_stand_in on the REFERENCE module:
+    pins the block's own arithmetic (edges, MLPs, BatchNorms, final layer) independent of torchvision."""
+    from oracle.dagem import plain_conv_stand_in
+    for si, (name, train) in enumerate({"dagem_plain_eval": False, "dagem_plain_train": True}.items()):
+        m = plain_conv_stand_in(ref.dagem.DAGEM(sync_bn=False, input_channels=64))
+        fill_parameters(m, 11 + si)
+        m.train(train)
+        x = rnd(800 + si, 2, 64, 8, 8, scale=0.7).requires_grad_(True)
+        y = m(x)
+        gy = rnd(810 + si, *y.shape)
+        y.backward(gy)
+        g = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        keys = sorted(g)
+        save(name, x=x, gy=gy, y=y, dx=x.grad, grad_keys=np.array(keys),
+             **{"g__" + k.replace(".", "__"): g[k] for k in keys})
+
+
 # ---------------------------------------------------------------- whole model
 def gen_model(ref):
     for name, mod, variant, nc, train, b, hw in [
@@ -212,4 +231,5 @@ if __name__ == "__main__":
     gen_evim(ref)
     gen_k3(ref)
     gen_iwp(ref)
+    gen_dagem(ref)
     gen_model(ref)

@@ -96,6 +96,10 @@ def test_dropin_import_paths():
         "m = KM_UNetV3(num_classes=20); assert len(m.state_dict()) == 920\n"
         "assert 'bridge_attention.deform_conv.weight' not in L(num_classes=3).state_dict()\n"
         "assert KANConv2d(4, 4, 3, padding=1).kanlayer.grid.shape == (36, 12)\n"
+        "for n in 'Cheby Fast GRAM Wav Jacobi ReLU Faster RBF'.split():\n"
+        "    cls = globals()[n + 'KANConv2d']          # KANConv2Dlayers.py:40-293: importable, refused with a reason\n"
+        "    try: cls(4, 4, 3, padding=1); raise SystemExit('constructed ' + n)\n"
+        "    except NotImplementedError as e: assert 'hot path' in str(e)\n"
         "print('ok')\n") % os.path.join(ROOT, "km-unet_amd", "dropin")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
@@ -120,3 +124,22 @@ def test_kanlinear_api_completeness():
     assert m.spline_weight.grad is not None and m.base_weight.grad is None
     with pytest.raises(NotImplementedError):
         m.update_grid(torch.randn(4, 36))
+
+
+def test_cosine_annealing_matches_torch_scheduler():
+    """train.CosineAnnealing == CosineAnnealingLR(T_max=200, eta_min=5e-4) (train_shanghai.py:398-399), also past T_max,
+    and a tensor learning rate is updated in place (what a captured graph needs)."""
+    import torch
+    from km_unet_amd.train import CosineAnnealing
+    p1, p2 = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
+    ref_opt = torch.optim.AdamW([p1], lr=1e-3, weight_decay=0.05)
+    ref = torch.optim.lr_scheduler.CosineAnnealingLR(ref_opt, T_max=200, eta_min=5e-4)
+    lr_t = torch.tensor(1e-3)
+    opt = torch.optim.AdamW([p2], lr=lr_t, weight_decay=0.05)
+    mine = CosineAnnealing(opt)
+    for epoch in range(450):
+        ref_opt.step()
+        ref.step()
+        mine.step()
+        assert abs(ref.get_last_lr()[0] - mine.get_last_lr()[0]) < 1e-9, epoch
+    assert opt.param_groups[0]["lr"] is lr_t            # same tensor object, updated in place

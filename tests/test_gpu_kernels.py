@@ -62,6 +62,33 @@ def test_k1_vs_oracle(B, Cin, Cout, H, W):
             dres=rel_err(d[4].grad, res.grad))
 
 
+@pytest.mark.parametrize("H,backward", [(256, True), (480, False)])
+def test_k1_vs_oracle_config34_sizes(H, backward):
+    """BASELINE.json configs[3] / [4] image sizes at site 1 (16 -> 16): 256x256 (LAPS) forward + backward, 480x480 (30x30
+    tile grid, levels 480/240/120/60) forward -- the oracle's unfolded temporaries make its backward at 480 a 10 GB affair."""
+    from oracle import kan as ok
+    ops = _ops()
+    gen = torch.Generator().manual_seed(H)
+    B, Cin, Cout = 1, 16, 16
+    x = (torch.randn(B, Cin, H, H, generator=gen) * 1.2).requires_grad_(backward)
+    bw = (torch.randn(Cout, Cin * 9, generator=gen) * 0.1).requires_grad_(backward)
+    sw = (torch.randn(Cout, Cin * 9, 8, generator=gen) * 0.1).requires_grad_(backward)
+    sc = (torch.randn(Cout, Cin * 9, generator=gen) * 0.5).requires_grad_(backward)
+    grid = ok.make_grid(Cin * 9)
+    gy = torch.randn(B, Cout, H, H, generator=gen)
+    with torch.set_grad_enabled(backward):
+        yo = ok.kan_conv2d(x, grid, bw, sw, sc)
+    d = [t.detach().to(DEV).requires_grad_(backward) for t in (x, bw, sw, sc)]
+    y = ops.kan_conv2d(d[0], grid.to(DEV), *d[1:])
+    errs = {"y": rel_err(y, yo)}
+    if backward:
+        yo.backward(gy)
+        y.backward(gy.to(DEV))
+        errs.update(dx=rel_err(d[0].grad, x.grad), dbw=rel_err(d[1].grad, bw.grad), dsw=rel_err(d[2].grad, sw.grad),
+                    dsc=rel_err(d[3].grad, sc.grad))
+    _report("k1 %dx%d" % (H, H), **errs)
+
+
 def test_k1_full_size_properties():
     """BASELINE size (B=8, 16->16 @128x128): size-independent properties instead of the (slow) oracle.
     (1) linearity in the base weights, (2) zero spline+base weights give zero, (3) translation of the
@@ -113,7 +140,10 @@ def test_k2_golden_backward(name):
     assert p["A"].grad.abs().max().item() == 0.0        # exact: A is a no-op parameter
 
 
-@pytest.mark.parametrize("B,C,Hs", [(2, 16, 32), (1, 16, 128), (2, 32, 64), (2, 64, 32), (1, 32, 20), (3, 64, 12)])
+@pytest.mark.parametrize("B,C,Hs", [(2, 16, 32), (1, 16, 128), (2, 32, 64), (2, 64, 32), (1, 32, 20), (3, 64, 12),
+                                    # configs[3] (256x256: L = 65 536 tokens) and configs[4] (480x480: ragged 30x30 / 15x15 /
+                                    # 7.5x7.5 tile grids at the three levels)
+                                    (1, 16, 256), (1, 16, 480), (1, 32, 240), (1, 64, 120)])
 def test_k2_vs_oracle(B, C, Hs):
     from oracle import hsmssd as oh
     ops = _ops()
@@ -158,6 +188,31 @@ def test_k2_softmax_stability_and_shift_invariance():
     assert rel_err(y3, y1[2:3]) < 1e-6
 
 
+@pytest.mark.parametrize("B,C,Hs", [(8, 16, 256), (2, 16, 480)])
+def test_k2_large_image_properties(B, C, Hs):
+    """configs[3] / [4] token counts at a full batch: every sample is independent, and the result is finite and
+    reproducible (two launches bit-identical: no float atomics on this path)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(Hs)
+    N = 64
+    x = torch.randn(B, C, Hs * Hs, generator=gen).to(DEV).requires_grad_(True)
+    w = [(torch.randn(3 * N, C, 1, generator=gen) / C ** 0.5).to(DEV).requires_grad_(True),
+         (torch.randn(3 * N, 1, 3, 3, generator=gen) * 0.4).to(DEV).requires_grad_(True),
+         (torch.randn(2 * C, C, 1, generator=gen) / C ** 0.5).to(DEV).requires_grad_(True),
+         (torch.randn(C, C, 1, generator=gen) / C ** 0.5).to(DEV).requires_grad_(True), torch.zeros(N, device=DEV), torch.ones(1, device=DEV)]
+    y, h = ops.hsmssd(x, *w)
+    gy = torch.randn(y.shape, generator=gen).to(DEV)
+    (dx,) = torch.autograd.grad((y * gy).sum(), x, retain_graph=True)
+    y2, h2 = ops.hsmssd(x, *w)
+    (dx2,) = torch.autograd.grad((y2 * gy).sum(), x)
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+    assert torch.equal(y, y2) and torch.equal(h, h2) and torch.equal(dx, dx2)
+    x1 = x[B - 1:].detach().contiguous().requires_grad_(True)
+    y1, _ = ops.hsmssd(x1, *w)
+    (dx1,) = torch.autograd.grad((y1 * gy[B - 1:]).sum(), x1)
+    assert rel_err(y1, y[B - 1:]) < 1e-6 and rel_err(dx1, dx[B - 1:]) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ K3
 @pytest.mark.parametrize("name", ["k3_default", "k3_large", "k3_b2", "k3_16"])
 def test_k3_golden(name):
@@ -181,7 +236,8 @@ def test_k3_golden(name):
     assert torch.equal(ix_o, g["ix0"]) and torch.equal(iy_o, g["iy0"])
 
 
-@pytest.mark.parametrize("B,H,W,std", [(8, 64, 64, 0.5), (2, 60, 60, 1.0), (1, 15, 30, 2.0), (4, 16, 16, 0.001)])
+@pytest.mark.parametrize("B,H,W,std", [(8, 64, 64, 0.5), (2, 60, 60, 1.0), (1, 15, 30, 2.0), (4, 16, 16, 0.001),
+                                       (1, 128, 128, 0.5), (1, 240, 240, 1.0), (1, 120, 120, 3.0)])   # configs[3] / [4] levels
 def test_k3_indices_bit_exact_large(B, H, W, std):
     """Index generation at full size incl. non power-of-two extents (config 5: 60/120/240)."""
     from oracle import dysample as od
@@ -527,6 +583,28 @@ def test_evim_block_golden(name, train):
     y = m(x)
     y.backward(g["gy"].to(DEV))
     _report(name, y=rel_err(y, g["y"]), dx=rel_err(x.grad, g["dx"]))
+
+
+@pytest.mark.parametrize("name,train", [("dagem_plain_eval", False), ("dagem_plain_train", True)])
+def test_dagem_block_golden_with_plain_conv_stand_in(name, train):
+    """The HIP model's DAGEM against the REFERENCE's DAGEM (DAGEM_md.py:56-111), the deformable conv replaced by the same plain
+    convolution on both sides (oracle.dagem.plain_conv_stand_in): everything in the block except torchvision's operator is
+    pinned by the reference itself; the operator alone stays 'parity unpinned' (test_k4_vs_oracle)."""
+    import km_unet_amd
+    from oracle.dagem import plain_conv_stand_in
+    from oracle.model import fill_parameters
+    g = load_golden(name)
+    m = fill_parameters(plain_conv_stand_in(km_unet_amd.DAGEM(sync_bn=False, input_channels=64)), 11 + int(train)).to(DEV)
+    m.train(train)
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    y.backward(g["gy"].to(DEV))
+    errs = {"y": rel_err(y, g["y"]), "dx": rel_err(x.grad, g["dx"])}
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(grads) == list(g["grad_keys"])
+    for k in g["grad_keys"]:
+        errs["d_" + k] = rel_err(grads[k], g["g__" + k.replace(".", "__")])
+    _report(name, **errs)
 
 
 def test_iwp_golden():

@@ -106,6 +106,25 @@ def test_model_matches_oracle_at_128():
     assert e < TOL and dcsi < 1e-3
 
 
+@pytest.mark.parametrize("variant,nc,shape", [("LAPS", 7, (1, 5, 256, 256)), ("SH", 5, (1, 5, 256, 256))])
+def test_model_matches_oracle_at_256(variant, nc, shape):
+    """configs[3]: the LAPS model at 256x256 (T=12 => num_classes 7; no DAGEM / DySample there, KM_UNetV3_LAPS.py), and the
+    SH model at 256x256 so that DySample / DAGEM run at the 32/64/128 levels too.  Eval mode, forward, vs the CPU oracle."""
+    import km_unet_amd
+    from oracle.model import KM_UNetV3 as Oracle, fill_parameters
+    o = fill_parameters(Oracle(num_classes=nc, variant=variant), 4).eval()
+    m = km_unet_amd.KM_UNetV3(num_classes=nc, variant=variant)
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.cuda().eval()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(31))
+    with torch.no_grad():
+        yo = o(x)
+        y = m(x.cuda())
+    e = rel_err(y, yo)
+    print("  [model256 %s] y=%.2e" % (variant, e))
+    assert e < TOL
+
+
 def test_hybrid_loss_and_csi_vs_oracle():
     """HybridLoss (train_shanghai.py:298-325; SSIM = torchmetrics restated => unpinned) and the CSI/POD/FAR/HSS
     scores (metrics.py) on the device vs the CPU oracle restatements."""
@@ -220,3 +239,30 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
     assert line["launch_mode"] == "hipGraph replay" and 0.0 < line["loss"] <= 1.5 * line["loss_first"] + 1e-3
     assert line["value"] > 0 and "roofline" in line and "cpu_baseline" not in line
+
+
+def test_bench_rccl_single_rank():
+    """The RCCL code path itself (init_process_group("nccl", device_id=...), the flat-bucket all-reduce between the two
+    captured graphs, barrier, MAX-reduce of the step time, destroy_process_group), run with ONE rank: RCCL accepts a 1-rank
+    communicator, and KMU_FORCE_DIST=1 makes bench.py take the distributed branch regardless of the world size.  What this
+    cannot show is xGMI traffic -- that needs the driver's multi-GPU node."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, KMU_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("KMU_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--size", "64", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["collective"].startswith("nccl all-reduce of")
+    assert line["launch_mode"] == "hipGraph replay" and 0.0 < line["loss"] <= 1.5 * line["loss_first"] + 1e-3

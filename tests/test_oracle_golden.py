@@ -64,6 +64,27 @@ def test_evim_block(name, train):
         assert abs(grads[k].double().abs().sum().item() - a) <= 1e-4 * max(a, 1e-6) + 1e-7, k
 
 
+@pytest.mark.parametrize("name,train", [("dagem_plain_eval", False), ("dagem_plain_train", True)])
+def test_dagem_block_with_plain_conv_stand_in(name, train):
+    """DAGEM_md.py:56-111 minus its one third-party operator: the reference's DAGEM and the oracle's, both with the deformable
+    conv replaced by oracle.dagem.plain_conv_stand_in -- pins the roll-edge products, the four Linear+BatchNorm1d MLPs and
+    the final aggregation layer (eval and batch-statistics mode)."""
+    from oracle.dagem import DAGEM, plain_conv_stand_in
+    g = load_golden(name)
+    m = plain_conv_stand_in(DAGEM(sync_bn=False, input_channels=64))
+    fill_parameters(m, 11 + int(train))
+    m.train(train)
+    x = g["x"].clone().requires_grad_(True)
+    y = m(x)
+    assert rel_err(y, g["y"]) < TOL
+    y.backward(g["gy"])
+    assert rel_err(x.grad, g["dx"]) < 5e-5
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(grads) == list(g["grad_keys"])
+    for k in g["grad_keys"]:
+        assert rel_err(grads[k], g["g__" + k.replace(".", "__")]) < 1e-4, k
+
+
 @pytest.mark.parametrize("name", ["k3_default", "k3_large", "k3_b2", "k3_16"])
 def test_k3_dysample(name):
     g = load_golden(name)

@@ -145,9 +145,22 @@ def run_diff(args):
             print("    first backward tensor that differs:", bb[0][0])
 
 
+def run_selfdiff(args):
+    """Replays of a graph whose weights and random numbers are fixed (--opt 0 --droppath 0) must be bit-identical: any tensor
+    whose norm changes between replays was written by a kernel with a race (float atomics excepted: DySample / deformable
+    conv backward scatter)."""
+    a = json.load(open(args.a))
+    base = a["rows"][0]
+    for i, row in enumerate(a["rows"][1:], start=1):
+        bad = [(n, v0, v) for n, v0, v in zip(a["names"], base, row) if v0 != v]
+        print("replay %d vs replay 0: %d of %d tensors differ at all" % (i, len(bad), len(a["names"])))
+        for n, v0, v in bad[:args.show]:
+            print("    %-70s %.9e  vs  %.9e  (rel %.1e)" % (n, v0, v, abs(v - v0) / max(abs(v0), 1e-30)))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=("losses", "trace", "diff"))
+    ap.add_argument("mode", choices=("losses", "trace", "diff", "selfdiff"))
     ap.add_argument("a", nargs="?")
     ap.add_argument("b", nargs="?")
     ap.add_argument("--droppath", type=int, default=1)
@@ -161,7 +174,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--show", type=int, default=12)
     args = ap.parse_args()
-    {"losses": run_losses, "trace": run_trace, "diff": run_diff}[args.mode](args)
+    {"losses": run_losses, "trace": run_trace, "diff": run_diff, "selfdiff": run_selfdiff}[args.mode](args)
 
 
 if __name__ == "__main__":
