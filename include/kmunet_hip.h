@@ -109,6 +109,12 @@ int kmu_hsmssd_fwd(const float* x, const float* w_bcdt, const float* w_dw, const
 int kmu_hsmssd_fwd_stage(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
                          const float* D, float* y, float* h, float* state, void* ws, size_t ws_bytes, int B, int C,
                          int N, int Hs, int stage, kmu_stream_t stream);
+/* The same three stages with the 1x1 projection and the depthwise 3x3 composed into one 3x3 convolution on the bf16 matrix
+ * core, split-bf16 ("bf16x3") operands (csrc/hsmssd_x3.inc; ~1e-5 relative; stage 0 also packs the composite weights into
+ * the workspace, which the stage-2 call of the same forward reads back: pass the same ws to all three). */
+int kmu_hsmssd_fwd_stage_x3(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
+                            const float* D, float* y, float* h, float* state, void* ws, size_t ws_bytes, int B, int C, int N,
+                            int Hs, int stage, kmu_stream_t stream);
 
 size_t kmu_hsmssd_bwd_ws_bytes(int B, int C, int N, int Hs);
 /* number of per-workgroup partial slabs written for d_w_bcdt / d_w_dw (caller sums over dim 0) */
@@ -341,6 +347,28 @@ int kmu_group_norm_fwd(const float* x, const float* gamma, const float* beta, fl
                        int C, int G, int HW, float eps, kmu_stream_t stream);
 int kmu_group_norm_bwd(const float* x, const float* gout, const float* gamma, const float* stats, float* dx,
                        float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW,
+                       kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Split-bf16 ("bf16x3") matrix-core variants of the 3x3 convolutions (csrc/conv3x3_x3.hip): every fp32 operand is split
+ * v = hi + lo into two bf16 and each product accumulated in fp32 as lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_bf16
+ * (~2^-16 relative product error; 5.3x the ceiling of the exact-fp32 MFMA used by kmu_kan_conv2d_fwd).
+ *   kmu_kan_conv2d_fwd_x3   convKAN/KANConv2Dlayers.py:15-37 + KANlayers.py:577-660, same contract as kmu_kan_conv2d_fwd
+ *                           (residual / ReLU epilogue); needs a (near-)uniform knot vector (|U[k] - (U[0] + k h)| < h/4:
+ *                           the layer's own grid, KANlayers.py:526-535) and Cin % 4 == 0
+ *   kmu_conv3x3_fwd_x3      nn.Conv2d(Cin, Cout, 3, padding=1) (+ bias): KM_UNetV3_SH.py:375 (conv_f), :430-446 (dec2[1],
+ *                           dec3[1], dec3[3]), :300-306 (MultiScaleFusion), DAGEM_md.py:43 (offset_conv); any Cin / Cout
+ * Packed weights: kmu_conv3x3_x3_pack_elems(kan, Cin, Cout) bf16 elements (2 bytes each), written by the pack calls from
+ * the layer's parameters (KAN: base_weight [Cout,9Cin], spline_weight [Cout,9Cin,8], spline_scaler [Cout,9Cin]; plain: weight
+ * [Cout,Cin,3,3]); repack whenever the parameters change.
+ * ------------------------------------------------------------------------------------ */
+size_t kmu_conv3x3_x3_pack_elems(int kan, int Cin, int Cout);
+int kmu_kan_pack_weights_x3(const float* base_weight, const float* spline_weight, const float* spline_scaler, void* wp,
+                            int Cin, int Cout, kmu_stream_t stream);
+int kmu_conv3x3_pack_weights_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream);
+int kmu_kan_conv2d_fwd_x3(const float* x, const float* knots, const void* wp, const float* residual, float* y, int B, int Cin,
+                          int Cout, int H, int W, int relu, kmu_stream_t stream);
+int kmu_conv3x3_fwd_x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                        kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

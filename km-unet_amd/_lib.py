@@ -31,6 +31,7 @@ SIGNATURES = {
     "kmu_hsmssd_fwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_hsmssd_fwd": (_I, [_P] * 10 + [_Z] + [_I] * 4 + [_P]),
     "kmu_hsmssd_fwd_stage": (_I, [_P] * 10 + [_Z] + [_I] * 5 + [_P]),
+    "kmu_hsmssd_fwd_stage_x3": (_I, [_P] * 10 + [_Z] + [_I] * 5 + [_P]),
     "kmu_hsmssd_bwd_stage": (_I, [_P] * 16 + [_Z] + [_I] * 5 + [_P]),
     "kmu_hsmssd_bwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_hsmssd_bwd_partials": (_I, [_I] * 3),
@@ -80,6 +81,11 @@ SIGNATURES = {
     "kmu_pwconv_bwd_input_add": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_partials": (_I, [_I]),
     "kmu_dwconv3x3_bwd_weight": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "kmu_conv3x3_x3_pack_elems": (_Z, [_I, _I, _I]),
+    "kmu_kan_pack_weights_x3": (_I, [_P] * 4 + [_I, _I, _P]),
+    "kmu_conv3x3_pack_weights_x3": (_I, [_P] * 2 + [_I, _I, _P]),
+    "kmu_kan_conv2d_fwd_x3": (_I, [_P] * 5 + [_I] * 6 + [_P]),
+    "kmu_conv3x3_fwd_x3": (_I, [_P] * 4 + [_I] * 5 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 

@@ -35,6 +35,7 @@ SOURCES = [
     ("shift3.hip", []),
     ("hybrid_loss.hip", []),
     ("contingency.hip", []),
+    ("conv3x3_x3.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

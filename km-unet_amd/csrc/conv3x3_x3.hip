@@ -1,0 +1,384 @@
+// 3x3 / stride 1 / pad 1 convolutions of gfx950's bf16 matrix core with SPLIT-bf16 ("bf16x3") operands:
+//
+//   K1  KANConv2d(x) = conv3x3(Phi(x), W')            convKAN/KANConv2Dlayers.py:15-37 + KANlayers.py:577-660
+//   plain nn.Conv2d(Cin, Cout, 3, padding=1)          KM_UNetV3_SH.py:375 (conv_f), :430-446 (dec2 / dec3), :287-311
+//                                                     (MultiScaleFusion), DAGEM_md.py:43 (offset_conv)
+//
+// Why: the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/kan_conv2d.hip) runs at the fp32 vector rate, 1/16 of the bf16
+// matrix rate.  Every fp32 operand is split  v = hi + lo,  hi = bf16(v), lo = bf16(v - hi)  (16 significant bits
+// together) and each product is accumulated in fp32 as  lo.hi + hi.lo + hi.hi  on v_mfma_f32_16x16x32_bf16: three MFMAs
+// at 16x the rate = 5.3x the fp32-MFMA ceiling, relative error of a product ~2^-16 (the dropped lo.lo term and the
+// truncation of lo), i.e. ~1e-5 of the result after a K = 1296..5184 accumulation -- two orders inside the 1e-3 parity
+// bound; the exact-fp32 kernels stay as the tested reference for these.
+//
+// Structure (one 256-thread workgroup = TH x TW output pixels, all Cout):
+//   for every chunk of 32 features (KAN: 4 input channels x 8 spline bases, then 32 channels of SiLU(x); plain: 32 input
+//   channels):   fill  F[halo position][32 features] as (hi, lo) bf16 in LDS   (Phi evaluated ONCE per input element,
+//                                                                                out-of-image positions hold Phi(0))
+//                for the 9 taps: A = 16 pixels x 32 features straight from F (one ds_read_b128 per lane and half),
+//                                B = packed weights (fragment order, L2-resident), 3 MFMAs per (pixel tile, channel tile).
+// LDS position stride = 160 B = 32 x 5: with an odd multiple of 32 B the four 16-lane groups of a ds_read_b128 fragment read
+// (16 positions x 16 B per k-group) cover all 64 banks exactly once (MI355X_MICROARCH.md, LDS table).
+#include "common.h"
+
+using kmu::floatx4;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+
+constexpr int PSTR = 160;        // bytes per halo position: hi[32] | lo[32] | 32 B pad
+constexpr int TABW = 12;         // per-span table: u[i-2..i+3], then the six knot-difference reciprocals of the de Boor triangle
+
+enum Mode { MODE_KAN = 0, MODE_PLAIN = 1 };
+
+__host__ __device__ inline int n_chunks(int mode, int Cin) {
+    return mode == MODE_KAN ? Cin / 4 + (Cin + 31) / 32 : (Cin + 31) / 32;
+}
+
+// ---- split one fp32 into (hi, lo) bf16 bit patterns -------------------------------------------------------------------
+__device__ __forceinline__ void split(float v, unsigned& hi, unsigned& lo) {
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    hi = (unsigned)__builtin_bit_cast(unsigned short, h);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+
+// ---- weight packs: wp[((chunk*9 + tap)*NT + nt)*2 + {hi,lo}][lane][8]; lane l holds B[k = 8(l>>4)+j][col = l&15] -------------
+__device__ __forceinline__ float kan_wprime(const float* bw, const float* sw, const float* sc, int Cin, int Cout, int o, int c,
+                                            int j, int tap) {   // j = 0: SiLU branch, 1..8: spline bases (as csrc/kan_conv2d.hip)
+    if (o >= Cout || c >= Cin) return 0.f;
+    const size_t f = (size_t)o * (Cin * 9) + c * 9 + tap;
+    return j == 0 ? bw[f] : sw[f * 8 + (j - 1)] * sc[f];
+}
+
+__global__ void pack_x3_kernel(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+                               unsigned short* __restrict__ wp, int mode, int Cin, int Cout, int NT, int NCH) {
+    const size_t total = (size_t)NCH * 9 * NT * 64 * 8;
+    const int nspl = mode == MODE_KAN ? Cin / 4 : 0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = e & 7, lane = (e >> 3) & 63;
+        size_t t = e >> 9;
+        const int nt = t % NT;
+        t /= NT;
+        const int tap = t % 9, chunk = (int)(t / 9);
+        const int k = 8 * (lane >> 4) + j, o = nt * 16 + (lane & 15);
+        float v;
+        if (mode == MODE_KAN) {
+            if (chunk < nspl) v = kan_wprime(w0, w1, w2, Cin, Cout, o, chunk * 4 + (k >> 3), 1 + (k & 7), tap);
+            else v = kan_wprime(w0, w1, w2, Cin, Cout, o, (chunk - nspl) * 32 + k, 0, tap);
+        } else {
+            const int c = chunk * 32 + k;
+            v = (o < Cout && c < Cin) ? w0[((size_t)o * Cin + c) * 9 + tap] : 0.f;
+        }
+        unsigned hi, lo;
+        split(v, hi, lo);
+        const size_t base = ((((size_t)chunk * 9 + tap) * NT + nt) * 2) * 512 + lane * 8 + j;
+        wp[base] = (unsigned short)hi;
+        wp[base + 512] = (unsigned short)lo;
+    }
+}
+
+// ---- per-span table of the layer's knot vector (KANlayers.py:526-535), spans i = 0..10: U[i] <= x < U[i+1] ------------------
+__device__ __forceinline__ float ext_knot(const float* knots, int idx) {      // idx in [-3, 14]: 3 virtual knots either side
+    if (idx < 0) return knots[0] + (float)idx * (knots[1] - knots[0]);
+    if (idx > 11) return knots[11] + (float)(idx - 11) * (knots[11] - knots[10]);
+    return knots[idx];
+}
+__device__ __forceinline__ void load_span_table(const float* __restrict__ knots, float* tab, float* kn, int tid) {
+    if (tid < 18) kn[tid] = ext_knot(knots, tid - 3);
+    if (tid < 11) {
+        float u[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) u[d] = ext_knot(knots, tid - 2 + d);     // u[2] = U[i], u[3] = U[i+1]
+        float* t = tab + tid * TABW;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) t[d] = u[d];
+        t[6] = 1.f / (u[3] - u[2]);
+        t[7] = 1.f / (u[3] - u[1]);
+        t[8] = 1.f / (u[4] - u[2]);
+        t[9] = 1.f / (u[3] - u[0]);
+        t[10] = 1.f / (u[4] - u[1]);
+        t[11] = 1.f / (u[5] - u[2]);
+    }
+}
+
+// The 8 cubic B-spline values of x as two 128-bit vectors of bf16 (hi parts, lo parts).  Same half-open span test as
+// KANlayers.py:593 on the layer's real knots; the triangle is csrc/kan_conv2d.hip's with the knot-difference divisions
+// replaced by multiplications with their tabulated reciprocals (<= 1 ulp apart per step).
+__device__ __forceinline__ void spline_bf16x8(float x, const float* tab, const float* kn, float u0, float inv_h, uintx4& vhi,
+                                              uintx4& vlo) {
+    int i = (int)floorf((x - u0) * inv_h);
+    i = min(max(i, -1), 11);
+    if (x < kn[i + 3]) --i;                    // kn[idx + 3] = U[idx]
+    else if (x >= kn[i + 4]) ++i;
+    const bool valid = (i >= 0) && (i <= 10) && (x >= kn[3]) && (x < kn[14]);
+    const int ic = min(max(i, 0), 10);
+    const floatx4 ta = *reinterpret_cast<const floatx4*>(tab + ic * TABW);
+    const floatx4 tb = *reinterpret_cast<const floatx4*>(tab + ic * TABW + 4);
+    const floatx4 tc = *reinterpret_cast<const floatx4*>(tab + ic * TABW + 8);
+    const float l1 = x - ta[2], r1 = ta[3] - x, l2 = x - ta[1], r2 = tb[0] - x, l3 = x - ta[0], r3 = tb[1] - x;
+    const float n0 = r1 * tb[2], n1 = l1 * tb[2];
+    float t = n0 * tb[3];
+    const float m0 = r1 * t;
+    float sv = l2 * t;
+    t = n1 * tc[0];
+    const float m1 = sv + r2 * t, m2 = l1 * t;
+    const float t0 = m0 * tc[1], t1 = m1 * tc[2], t2 = m2 * tc[3];
+    const float c0 = r1 * t0, c1 = l3 * t0 + r2 * t1, c2 = l2 * t1 + r3 * t2, c3 = l1 * t2;     // N_{i-3..i,3}(x)
+    unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+    split(c0, h0, q0);
+    split(c1, h1, q1);
+    split(c2, h2, q2);
+    split(c3, h3, q3);
+    unsigned long long qh = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
+    unsigned long long ql = (unsigned long long)(q0 | (q1 << 16)) | ((unsigned long long)(q2 | (q3 << 16)) << 32);
+    if (!valid) qh = ql = 0ull;
+    // place the quad at basis slots a = i-3 .. i of the 8-slot vector (slots outside 0..7 fall off either end)
+    const int s = ic - 3;                      // -3 .. 7, in 16-bit slots
+    unsigned long long hl, hh, ll, lh;
+    if (s < 0) {
+        hl = qh >> (16 * -s), hh = 0ull, ll = ql >> (16 * -s), lh = 0ull;
+    } else if (s == 0) {
+        hl = qh, hh = 0ull, ll = ql, lh = 0ull;
+    } else if (s < 4) {
+        hl = qh << (16 * s), hh = qh >> (64 - 16 * s), ll = ql << (16 * s), lh = ql >> (64 - 16 * s);
+    } else {
+        hl = 0ull, hh = qh << (16 * (s - 4)), ll = 0ull, lh = ql << (16 * (s - 4));
+    }
+    vhi = uintx4{(unsigned)hl, (unsigned)(hl >> 32), (unsigned)hh, (unsigned)(hh >> 32)};
+    vlo = uintx4{(unsigned)ll, (unsigned)(ll >> 32), (unsigned)lh, (unsigned)(lh >> 32)};
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+template <int TH, int TW>
+struct Geo {
+    static constexpr int RS = TW + 2, HT = (TH + 2) * RS;
+    static constexpr int FBYTES = HT * PSTR;
+    static constexpr int LDS_BYTES = FBYTES + (11 * TABW + 32) * 4;
+};
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+template <int MODE, int TH, int TW, int WM, int WN, int NREP>
+__global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ knots,
+                                                             const bf16x8* __restrict__ wp, const float* __restrict__ bias,
+                                                             const float* __restrict__ residual, float* __restrict__ y, int Cin,
+                                                             int Cout, int H, int W, int NT, int tilesX, int relu) {
+    using G = Geo<TH, TW>;
+    constexpr int RS = G::RS, HT = G::HT, MF = TH * TW / 16, MREP = MF / WM, SPR = TW / 16;
+    static_assert(WM * WN == 4 && MF % WM == 0, "4 waves over the pixel fragments / channel tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* F = smem;
+    float* tab = reinterpret_cast<float*>(smem + G::FBYTES);
+    float* kn = tab + 11 * TABW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ty0 = (blockIdx.x / tilesX) * TH, tx0 = (blockIdx.x % tilesX) * TW;
+    const int b = blockIdx.z;
+    const int nt0 = (blockIdx.y * WN + wn) * NREP;
+    const int li = lane & 15, lg = lane >> 4;
+
+    float u0 = 0.f, inv_h = 0.f;
+    if (MODE == MODE_KAN) {
+        load_span_table(knots, tab, kn, tid);
+        u0 = knots[0];
+        inv_h = 11.f / (knots[11] - knots[0]);
+    }
+
+    floatx4 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[m][n] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    int aoff[MREP];   // byte offset of this lane's A row (tap (0,0)) for each of its pixel fragments
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int seg = wm * MREP + m;
+        aoff[m] = ((seg / SPR) * RS + (seg % SPR) * 16 + li) * PSTR + lg * 16;
+    }
+
+    const float* xb = x + (size_t)b * Cin * H * W;
+    const int nspl = MODE == MODE_KAN ? Cin / 4 : 0;
+    const int NCH = nspl + (Cin + 31) / 32;
+    for (int ch = 0; ch < NCH; ++ch) {
+        __syncthreads();   // previous chunk's fragment reads done (and the span table visible on the first trip)
+        if (MODE == MODE_KAN && ch < nspl) {
+            for (int e = tid; e < 4 * HT; e += 256) {
+                const int q = e / HT, pos = e - q * HT;
+                const int hy = pos / RS, hx = pos - hy * RS;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1, c = ch * 4 + q;
+                float xv = 0.f;   // out-of-image taps see x = 0 -> Phi(0) (reference: F.unfold zero padding)
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) xv = xb[((size_t)c * H + gy) * W + gx];
+                uintx4 vh, vl;
+                spline_bf16x8(xv, tab, kn, u0, inv_h, vh, vl);
+                unsigned char* dst = F + pos * PSTR + q * 16;
+                *reinterpret_cast<uintx4*>(dst) = vh;
+                *reinterpret_cast<uintx4*>(dst + 64) = vl;
+            }
+        } else {
+            const int c0 = (ch - nspl) * 32;
+            for (int e = tid; e < 4 * HT; e += 256) {
+                const int q = e / HT, pos = e - q * HT;
+                const int hy = pos / RS, hx = pos - hy * RS;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                unsigned hv[8], lv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + q * 8 + j;
+                    float v = 0.f;
+                    if (in && c < Cin) {
+                        v = xb[((size_t)c * H + gy) * W + gx];
+                        if (MODE == MODE_KAN) v = silu_f(v);
+                    }
+                    split(v, hv[j], lv[j]);
+                }
+                unsigned char* dst = F + pos * PSTR + q * 16;
+                *reinterpret_cast<uintx4*>(dst) = uintx4{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
+                *reinterpret_cast<uintx4*>(dst + 64) = uintx4{lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16), lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16)};
+            }
+        }
+        __syncthreads();
+        const bf16x8* wpc = wp + (((size_t)ch * 9) * NT + nt0) * 128 + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = ((tap / 3) * RS + (tap % 3)) * PSTR;
+            bf16x8 bh[NREP], bl[NREP];
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+                bh[n] = wpc[((size_t)tap * NT + n) * 128];
+                bl[n] = wpc[((size_t)tap * NT + n) * 128 + 64];
+            }
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff + 64);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: lane holds 4 consecutive pixels (rows lg*4 + r of the C tile) of output channel nt*16 + li
+    const bool vec_ok = (W & 3) == 0;
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int seg = wm * MREP + m;
+        const int gy = ty0 + seg / SPR, px0 = tx0 + (seg % SPR) * 16 + lg * 4;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const int o = (nt0 + n) * 16 + li;
+            if (o >= Cout || gy >= H || px0 >= W) continue;
+            const size_t idx = (((size_t)b * Cout + o) * H + gy) * W + px0;
+            floatx4 v = acc[m][n];
+            if (bias) v += bias[o];
+            if (vec_ok && px0 + 3 < W) {
+                if (residual) v += *reinterpret_cast<const floatx4*>(residual + idx);
+                if (relu) v = floatx4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<floatx4*>(y + idx) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (px0 + r < W) {
+                        float s = v[r];
+                        if (residual) s += residual[idx + r];
+                        if (relu) s = fmaxf(s, 0.f);
+                        y[idx + r] = s;
+                    }
+            }
+        }
+    }
+}
+
+template <int MODE, int TH, int TW, int WM, int WN, int NREP>
+int launch_fwd(const float* x, const float* knots, const void* wp, const float* bias, const float* residual, float* y, int B,
+               int Cin, int Cout, int H, int W, int relu, hipStream_t st) {
+    using G = Geo<TH, TW>;
+    const int NT = kmu::cdiv(Cout, 16);
+    const int tilesX = kmu::cdiv(W, TW), tilesY = kmu::cdiv(H, TH);
+    dim3 grid(tilesX * tilesY, NT / (WN * NREP), B);
+    auto kern = conv3x3_x3_fwd_kernel<MODE, TH, TW, WM, WN, NREP>;
+    KMU_MAX_LDS(kern, G::LDS_BYTES);
+    hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, st, x, knots, (const bf16x8*)wp, bias, residual, y, Cin, Cout, H, W, NT,
+                       tilesX, relu);
+    return kmu::launch_status(MODE == MODE_KAN ? "kan_conv2d_fwd_x3" : "conv3x3_fwd_x3");
+}
+
+// tile / wave layout: all Cout channel tiles in one workgroup (the feature tile is evaluated once), enough workgroups to fill
+// 256 CUs where the image allows it
+template <int MODE>
+int dispatch_fwd(const float* x, const float* knots, const void* wp, const float* bias, const float* residual, float* y, int B,
+                 int Cin, int Cout, int H, int W, int relu, hipStream_t st) {
+    const int NT = kmu::cdiv(Cout, 16);
+    const long px = (long)B * H * W;
+    const bool big = px >= 65536 && W >= 32;
+    if (NT == 1) {
+        if (big) return launch_fwd<MODE, 8, 32, 4, 1, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
+        return launch_fwd<MODE, 4, 16, 4, 1, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
+    }
+    if (NT == 2) {
+        if (big) return launch_fwd<MODE, 8, 32, 2, 2, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
+        return launch_fwd<MODE, 4, 16, 2, 2, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
+    }
+    if (NT == 4) {
+        if (big) return launch_fwd<MODE, 8, 16, 1, 4, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
+        return launch_fwd<MODE, 4, 16, 1, 4, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
+    }
+    if (NT % 4 == 0) return launch_fwd<MODE, 4, 16, 1, 4, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);  // grid.y = NT/4
+    if (NT % 2 == 0) return launch_fwd<MODE, 4, 16, 2, 2, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
+    return launch_fwd<MODE, 4, 16, 4, 1, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);                    // grid.y = NT
+}
+
+}  // namespace
+
+extern "C" size_t kmu_conv3x3_x3_pack_elems(int kan, int Cin, int Cout) {
+    return (size_t)n_chunks(kan ? MODE_KAN : MODE_PLAIN, Cin) * 9 * kmu::cdiv(Cout, 16) * 2 * 512;
+}
+
+extern "C" int kmu_kan_pack_weights_x3(const float* base_weight, const float* spline_weight, const float* spline_scaler,
+                                       void* wp, int Cin, int Cout, kmu_stream_t stream) {
+    KMU_REQUIRE(base_weight && spline_weight && spline_scaler && wp, "kan_pack_weights_x3: null pointer");
+    KMU_REQUIRE(Cin > 0 && Cout > 0 && Cin % 4 == 0, "kan_pack_weights_x3: Cin=%d must be a positive multiple of 4", Cin);
+    const int NT = kmu::cdiv(Cout, 16), NCH = n_chunks(MODE_KAN, Cin);
+    const size_t n = (size_t)NCH * 9 * NT * 512;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, base_weight, spline_weight, spline_scaler,
+                       (unsigned short*)wp, (int)MODE_KAN, Cin, Cout, NT, NCH);
+    return kmu::launch_status("kan_pack_weights_x3");
+}
+
+extern "C" int kmu_conv3x3_pack_weights_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream) {
+    KMU_REQUIRE(weight && wp, "conv3x3_pack_weights_x3: null pointer");
+    KMU_REQUIRE(Cin > 0 && Cout > 0, "conv3x3_pack_weights_x3: bad dims Cin=%d Cout=%d", Cin, Cout);
+    const int NT = kmu::cdiv(Cout, 16), NCH = n_chunks(MODE_PLAIN, Cin);
+    const size_t n = (size_t)NCH * 9 * NT * 512;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (const float*)nullptr,
+                       (const float*)nullptr, (unsigned short*)wp, (int)MODE_PLAIN, Cin, Cout, NT, NCH);
+    return kmu::launch_status("conv3x3_pack_weights_x3");
+}
+
+extern "C" int kmu_kan_conv2d_fwd_x3(const float* x, const float* knots, const void* wp, const float* residual, float* y, int B,
+                                     int Cin, int Cout, int H, int W, int relu, kmu_stream_t stream) {
+    KMU_REQUIRE(x && knots && wp && y, "kan_conv2d_fwd_x3: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && B <= 65535 && Cin % 4 == 0, "kan_conv2d_fwd_x3: bad dims");
+    return dispatch_fwd<MODE_KAN>(x, knots, wp, nullptr, residual, y, B, Cin, Cout, H, W, relu, (hipStream_t)stream);
+}
+
+extern "C" int kmu_conv3x3_fwd_x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int H,
+                                  int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && wp && y, "conv3x3_fwd_x3: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && B <= 65535, "conv3x3_fwd_x3: bad dims");
+    return dispatch_fwd<MODE_PLAIN>(x, nullptr, wp, bias, nullptr, y, B, Cin, Cout, H, W, 0, (hipStream_t)stream);
+}

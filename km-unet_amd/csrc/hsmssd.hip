@@ -656,6 +656,7 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
     return rc;
 }
 
+#include "hsmssd_x3.inc"
 #include "hsmssd_bwd.inc"
 
 }  // namespace
@@ -664,19 +665,26 @@ extern "C" size_t kmu_hsmssd_state_elems(int B, int C, int N) { return (size_t)B
 
 extern "C" size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs) {
     int tx;
-    const int T = tiles_for(C, Hs, &tx);
-    return (size_t)B * T * ((size_t)2 * N + (size_t)N * C) * sizeof(float);
+    int T = tiles_for(C, Hs, &tx);
+    const int T3 = C == 16 ? tiles_x3<16>(Hs, &tx) : (C == 32 ? tiles_x3<32>(Hs, &tx) : tiles_x3<64>(Hs, &tx));
+    if (T3 > T) T = T3;     // one size serves both the exact-fp32 and the bf16x3 tilings; the latter appends its packed weights
+    return (size_t)B * T * ((size_t)2 * N + (size_t)N * C) * sizeof(float) + pack_x3_elems(C) * 2;
 }
 
 static int hsmssd_fwd_stages(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
                              const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
-                             size_t ws_bytes, int B, int C, int N, int Hs, int stages, kmu_stream_t stream) {
+                             size_t ws_bytes, int B, int C, int N, int Hs, int stages, kmu_stream_t stream, bool x3 = false) {
     KMU_REQUIRE(x && w_bcdt && w_dw && w_hz && w_out && D && y && h && state && ws, "hsmssd_fwd: null pointer");
     KMU_REQUIRE(N == NS, "hsmssd_fwd: state_dim=%d unsupported (kernels are built for 64)", N);
     KMU_REQUIRE(C == 16 || C == 32 || C == 64, "hsmssd_fwd: C=%d unsupported (16/32/64)", C);
     KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0, "hsmssd_fwd: bad dims");
     KMU_REQUIRE(ws_bytes >= kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs), "hsmssd_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (x3) {
+        if (C == 16) return fwd_impl_x3<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
+        if (C == 32) return fwd_impl_x3<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
+        return fwd_impl_x3<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
+    }
     if (C == 16) return fwd_impl<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
     if (C == 32) return fwd_impl<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
     return fwd_impl<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
@@ -738,6 +746,13 @@ extern "C" int kmu_layernorm1d_bwd(const float* x, const float* weight, const fl
         hipLaunchKernelGGL(ln1d_bwd_kernel, grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial, d_bias_partial, C,
                            L);
     return kmu::launch_status("layernorm1d_bwd");
+}
+
+extern "C" int kmu_hsmssd_fwd_stage_x3(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                                       const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
+                                       size_t ws_bytes, int B, int C, int N, int Hs, int stage, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_fwd_stage_x3: stage must be 0 (pack + pass 1), 1 (gate) or 2 (pass 2)");
+    return hsmssd_fwd_stages(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true);
 }
 
 // ---- backward entry points (kernels in hsmssd_bwd.inc) -------------------------------------------

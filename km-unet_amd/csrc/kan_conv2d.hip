@@ -109,7 +109,7 @@ __device__ __forceinline__ float wprime(const float* bw, const float* sw, const 
 __global__ void kan_pack_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
                                 const float* __restrict__ sc, float* __restrict__ wp, float* __restrict__ wq, int Cin,
                                 int Cout, int CG, int NT, int OG, int CT) {
-    const size_t nf = (size_t)CG * 81 * NT * 64, nb = (size_t)OG * 81 * CT * 64;
+    const size_t nf = wp ? (size_t)CG * 81 * NT * 64 : 0, nb = (size_t)OG * 81 * CT * 64;   // wp == nullptr: backward pack only
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nf + (wq ? nb : 0);
          e += (size_t)gridDim.x * blockDim.x) {
         if (e < nf) {
@@ -589,10 +589,10 @@ extern "C" size_t kmu_kan_pack_bwd_elems(int Cin, int Cout) {
 
 extern "C" int kmu_kan_pack_weights(const float* base_weight, const float* spline_weight, const float* spline_scaler,
                                     float* wp_fwd, float* wp_bwd, int Cin, int Cout, kmu_stream_t stream) {
-    KMU_REQUIRE(base_weight && spline_weight && spline_scaler && wp_fwd, "kan_pack_weights: null pointer");
+    KMU_REQUIRE(base_weight && spline_weight && spline_scaler && (wp_fwd || wp_bwd), "kan_pack_weights: null pointer");
     KMU_REQUIRE(Cin > 0 && Cout > 0, "kan_pack_weights: bad dims Cin=%d Cout=%d", Cin, Cout);
     const int CG = kmu::cdiv(Cin, 4), NT = kmu::cdiv(Cout, 16), OG = kmu::cdiv(Cout, 4), CT = kmu::cdiv(Cin, 16);
-    const size_t n = kmu_kan_pack_fwd_elems(Cin, Cout) + (wp_bwd ? kmu_kan_pack_bwd_elems(Cin, Cout) : 0);
+    const size_t n = (wp_fwd ? kmu_kan_pack_fwd_elems(Cin, Cout) : 0) + (wp_bwd ? kmu_kan_pack_bwd_elems(Cin, Cout) : 0);
     const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(kan_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, base_weight, spline_weight,
                        spline_scaler, wp_fwd, wp_bwd, Cin, Cout, CG, NT, OG, CT);

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1, gate_mlp, group_norm
+from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1, conv3x3, gate_mlp, group_norm
 
 
 import os as _os
@@ -220,8 +220,8 @@ class MultiScaleFusion(nn.Module):
         self.fusion = nn.Sequential(nn.Conv2d(co * 3, co, 1), nn.Conv2d(co, co, 3, padding=1), ChannelAttention(co, reduction))
 
     def forward(self, features):
-        x = torch.cat([F.silu(group_norm(blk[0](f), blk[1])) for blk, f in zip(self.blocks, features)], dim=1)
-        return self.fusion[2](self.fusion[1](conv1x1(x, self.fusion[0])))
+        x = torch.cat([F.silu(group_norm(conv3x3(f, blk[0]), blk[1])) for blk, f in zip(self.blocks, features)], dim=1)
+        return self.fusion[2](conv3x3(conv1x1(x, self.fusion[0]), self.fusion[1]))
 
 
 class LocalContrastAttention(nn.Module):
@@ -278,12 +278,13 @@ class KM_UNetV3(nn.Module):
         return fusion([a, b, b])                 # third level is e2 again (KM_UNetV3_SH.py:495,509)
 
     def forward(self, x):
-        x = self.conv_f(x.float())
+        x = conv3x3(x.float(), self.conv_f)
         e1 = self.lca1(self.enc1(x))
         e2 = self.lca2(self.enc2(e1))
         e3 = self.lca3(self.enc3(e2))
         d1 = self.dec1(self.bridge_attention(e3) if self.variant == "SH" else e3)
         d1 = torch.cat([d1, self._pyramid(self.attention1, e1, e2, d1)], dim=1)
-        d2 = self.dec2(d1)
+        d2 = self.dec2[2](conv3x3(self.dec2[0](d1), self.dec2[1]))
         d2 = torch.cat([d2, self._pyramid(self.attention2, e1, e2, d2)], dim=1)
-        return self.activation(group_norm(self.dec3(d2), self.output_norm))
+        d3 = conv3x3(self.dec3[2](conv3x3(self.dec3[0](d2), self.dec3[1])), self.dec3[3])
+        return self.activation(group_norm(d3, self.output_norm))

@@ -38,6 +38,16 @@ def conv1x1(x, conv, gelu_in=False):
     return y.view(b, co, h, w)
 
 
+def conv3x3(x, conv):
+    """A plain nn.Conv2d: 3x3 / stride 1 / padding 1 / dense ones run on the split-bf16 matrix-core kernel
+    (csrc/conv3x3_x3.hip; MIOpen served them with NCHW<->NHWC transposes around an implicit GEMM chosen by a timing search);
+    any other geometry (the 5x5 / 7x7 convs of MultiScaleFusion) stays on MIOpen.  KMU_GLUE_TORCH=conv3x3 keeps MIOpen."""
+    if ("conv3x3" not in _TORCH_GLUE and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1):
+        return ops.conv3x3(x, conv.weight, conv.bias)
+    return conv(x)
+
+
 def gate_mlp(p, lin1, lin2, act1, act2="sigmoid"):
     """act2(lin2(act1(lin1(p)))) for pooled [B, I] vectors; lin1/lin2 are nn.Linear or 1x1 nn.Conv2d modules
     (csrc/gate_mlp.hip: one launch each way).  KMU_GLUE_TORCH=gate_mlp keeps the ATen sequence."""
@@ -349,7 +359,7 @@ class DAGEM(nn.Module):
         ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1).permute(0, 2, 3, 4, 1).reshape(-1, 2 * c)
         ue = self.edge_update_func(ef).view(b, h, w, 4, c // 2).permute(0, 4, 1, 2, 3).reshape(-1, 4)
         ue = self.update_edge_reduce_func(ue).view(b, c // 2, h, w)
-        deformed = self.deform_conv(x, self.offset_conv(x)) + x
+        deformed = self.deform_conv(x, conv3x3(x, self.offset_conv)) + x
         fa = self.final_aggregation_layer
         return fa[2](fa[1](conv1x1(torch.cat((deformed, vert * ue), 1), fa[0])))
 

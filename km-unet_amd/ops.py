@@ -73,7 +73,16 @@ def colsum(*partials):
 
 
 # ------------------------------------------------------------------------------------------ K1
-_GRID_OK = set()
+import os as _os
+
+# Matrix-core arithmetic of the 3x3 contractions (K1 and the plain 3x3 convolutions):
+#   "bf16x3" (default): split-bf16 operands on v_mfma_f32_16x16x32_bf16 (csrc/conv3x3_x3.hip), ~1e-5 relative to the result
+#   "f32"             : exact fp32 on v_mfma_f32_16x16x4_f32 (csrc/kan_conv2d.hip) -- the reference the bf16x3 kernels are tested against
+K1_MATH = _os.environ.get("KMU_K1_MATH", "bf16x3")
+# K2 forward: "bf16x3" = projection and depthwise 3x3 composed into one 3x3 convolution on the bf16 matrix core
+# (csrc/hsmssd_x3.inc); "f32" = the exact-fp32 projection + LDS stencil kernels (csrc/hsmssd.hip)
+K2_MATH = _os.environ.get("KMU_K2_MATH", "bf16x3")
+_GRID_OK = {}
 
 
 def _check_grid(grid):
@@ -88,8 +97,12 @@ def _check_grid(grid):
                                "the HIP kernel supports one shared knot vector only")
         if not bool((grid[0, 1:] > grid[0, :-1]).all()):
             raise RuntimeError("KANConv2d: knots must be strictly increasing")
-        _GRID_OK.add(key)
-    return grid[0].contiguous()
+        # the bf16x3 kernel finds the knot span by one multiply + one correction step: needs knots within h/4 of uniform
+        # (true for the layer's own grid, KANlayers.py:526-535; anything else runs on the exact-fp32 kernel's 12-compare search)
+        u = grid[0].double().cpu()
+        h = (u[11] - u[0]) / 11
+        _GRID_OK[key] = bool(((u - (u[0] + h * torch.arange(12, dtype=torch.float64))).abs() < 0.25 * h).all())
+    return grid[0].contiguous(), _GRID_OK[key]
 
 
 class KanConv2dFn(torch.autograd.Function):
@@ -100,22 +113,31 @@ class KanConv2dFn(torch.autograd.Function):
         lib = _lib.load()
         x = _f32c(x, "x")
         base_w, spline_w, scaler = _f32c(base_w, "base_weight"), _f32c(spline_w, "spline_weight"), _f32c(scaler, "spline_scaler")
-        knots = _check_grid(grid)
+        knots, uniform = _check_grid(grid)
         B, Cin, H, W = x.shape
         Cout = base_w.shape[0]
         if base_w.shape[1] != Cin * 9:
             raise RuntimeError("KANConv2d: base_weight %s does not match Cin=%d, 3x3" % (tuple(base_w.shape), Cin))
         need_bwd = any(ctx.needs_input_grad)
-        wp_f = torch.empty(lib.kmu_kan_pack_fwd_elems(Cin, Cout), device=x.device, dtype=torch.float32)
+        x3 = K1_MATH == "bf16x3" and uniform and Cin % 4 == 0
+        wp_f = None if x3 else torch.empty(lib.kmu_kan_pack_fwd_elems(Cin, Cout), device=x.device, dtype=torch.float32)
         wp_b = torch.empty(lib.kmu_kan_pack_bwd_elems(Cin, Cout), device=x.device, dtype=torch.float32) if need_bwd else None
         st = _stream()
-        _lib.check(lib.kmu_kan_pack_weights(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wp_f), _ptr(wp_b), Cin, Cout, st),
-                   "kmu_kan_pack_weights")
+        if wp_f is not None or wp_b is not None:
+            _lib.check(lib.kmu_kan_pack_weights(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wp_f), _ptr(wp_b), Cin, Cout, st),
+                       "kmu_kan_pack_weights")
         y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
         if residual is not None:
             residual = _f32c(residual, "residual")
-        _lib.check(_call(("kan_conv2d_fwd", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_fwd, _ptr(x), _ptr(knots), _ptr(wp_f),
-                         _ptr(residual), _ptr(y), B, Cin, Cout, H, W, 1 if relu else 0, st), "kmu_kan_conv2d_fwd")
+        if x3:
+            wp3 = torch.empty(lib.kmu_conv3x3_x3_pack_elems(1, Cin, Cout), device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.kmu_kan_pack_weights_x3(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wp3), Cin, Cout, st),
+                       "kmu_kan_pack_weights_x3")
+            _lib.check(_call(("kan_conv2d_fwd_x3", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_fwd_x3, _ptr(x), _ptr(knots), _ptr(wp3),
+                             _ptr(residual), _ptr(y), B, Cin, Cout, H, W, 1 if relu else 0, st), "kmu_kan_conv2d_fwd_x3")
+        else:
+            _lib.check(_call(("kan_conv2d_fwd", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_fwd, _ptr(x), _ptr(knots), _ptr(wp_f),
+                             _ptr(residual), _ptr(y), B, Cin, Cout, H, W, 1 if relu else 0, st), "kmu_kan_conv2d_fwd")
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, knots, spline_w, scaler, wp_b, y if relu else None)
@@ -150,6 +172,43 @@ class KanConv2dFn(torch.autograd.Function):
 
 def kan_conv2d(x, grid, base_weight, spline_weight, spline_scaler, residual=None, relu=False):
     return KanConv2dFn.apply(x, grid, base_weight, spline_weight, spline_scaler, residual, relu)
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """nn.Conv2d(Cin, Cout, 3, stride 1, padding 1)(x) on the split-bf16 matrix-core kernel (csrc/conv3x3_x3.hip):
+    KM_UNetV3_SH.py:375 (conv_f), :430-446 (dec2[1], dec3[1], dec3[3]), :300-306 (MultiScaleFusion), DAGEM_md.py:43."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, weight = _f32c(x, "x"), _f32c(weight, "weight")
+        bias = _f32c(bias, "bias") if bias is not None else None
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        if tuple(weight.shape) != (Cout, Cin, 3, 3):
+            raise RuntimeError("conv3x3: weight %s does not match Cin=%d, 3x3" % (tuple(weight.shape), Cin))
+        st = _stream()
+        wp = torch.empty(lib.kmu_conv3x3_x3_pack_elems(0, Cin, Cout), device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.kmu_conv3x3_pack_weights_x3(_ptr(weight), _ptr(wp), Cin, Cout, st), "kmu_conv3x3_pack_weights_x3")
+        y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("conv3x3_fwd_x3", (B, Cin, Cout, H, W)), lib.kmu_conv3x3_fwd_x3, _ptr(x), _ptr(wp), _ptr(bias), _ptr(y),
+                         B, Cin, Cout, H, W, st), "kmu_conv3x3_fwd_x3")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
+        dx, dw, db = torch.ops.aten.convolution_backward(dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1],
+                                                         [1, 1], False, [0, 0], 1, mask)
+        return dx, dw, (db if mask[2] else None)
+
+
+def conv3x3(x, weight, bias=None):
+    return Conv3x3Fn.apply(x, weight, bias)
 
 
 # ------------------------------------------------------------------------------------------ K2
@@ -211,8 +270,10 @@ class HsmssdFn(torch.autograd.Function):
         nbytes = lib.kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs)
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
         st = _stream()
+        x3 = K2_MATH == "bf16x3"
+        fn = lib.kmu_hsmssd_fwd_stage_x3 if x3 else lib.kmu_hsmssd_fwd_stage
         for stage, nm in enumerate(("hsmssd_fwd_pass1", "hsmssd_fwd_gate", "hsmssd_fwd_pass2")):   # one kernel per call
-            _lib.check(_call((nm, (B, C, Hs)), lib.kmu_hsmssd_fwd_stage, _ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
+            _lib.check(_call((nm + ("_x3" if x3 and stage != 1 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
                              _ptr(w_out), _ptr(D), _ptr(y), _ptr(h), _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, stage, st),
                        "kmu_hsmssd_fwd_stage")
         ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)

@@ -81,8 +81,10 @@ def test_dagem_block_with_plain_conv_stand_in(name, train):
     assert rel_err(x.grad, g["dx"]) < 5e-5
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     assert sorted(grads) == list(g["grad_keys"])
-    for k in g["grad_keys"]:
-        assert rel_err(grads[k], g["g__" + k.replace(".", "__")]) < 1e-4, k
+    gmax = max(g["g__" + k.replace(".", "__")].abs().max().item() for k in g["grad_keys"])
+    for k in g["grad_keys"]:       # biases in front of a batch-statistics BatchNorm: exactly-zero gradient, noise in the fixture
+        ref = g["g__" + k.replace(".", "__")]
+        assert (grads[k].double() - ref.double()).abs().max().item() / max(ref.abs().max().item(), 1e-4 * gmax) < 1e-4, k
 
 
 @pytest.mark.parametrize("name", ["k3_default", "k3_large", "k3_b2", "k3_16"])
