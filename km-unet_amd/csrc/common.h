@@ -72,6 +72,13 @@ __device__ __forceinline__ void mfma_tied(floatx4& acc, float a, float b) {
 }
 __device__ __forceinline__ void mfma_drain(floatx4& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
 
+// The same for the bf16 matrix core (v_mfma_f32_16x16x32_bf16: 8 bf16 per lane for A and B).  Used where the ISA screen
+// (tools/check_mfma_overlap.py) catches hipcc emitting a partially overlapping vdst / SrcC pair for the builtin.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mfma_bf16_tied(floatx4& acc, bf16x8_t a, bf16x8_t b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 }  // namespace kmu
 
 // Raise a kernel's dynamic-LDS limit once per call site / template instantiation (never during a later

@@ -41,6 +41,17 @@ def _call(key, fn, *args):
     return rc
 
 
+# Test support (tests/, smoke()): when set to a list, every op that applies a ReLU appends its branch mask (output > 0), in
+# execution order.  The parity checks hand these masks to the oracle so that both sides differentiate the SAME piecewise-linear
+# branch (oracle/ties.py: a pre-activation within rounding of zero may take either branch in two correct implementations).
+RELU_TAP = None
+
+
+def _tap_relu(t):
+    if RELU_TAP is not None:
+        RELU_TAP.append((t.detach() > 0).cpu())
+
+
 def _f32c(t, name):
     if not t.is_cuda:
         raise RuntimeError("%s: %s is on %s; the KM-UNet hot path only runs as HIP kernels on an MI355X "
@@ -138,6 +149,8 @@ class KanConv2dFn(torch.autograd.Function):
         else:
             _lib.check(_call(("kan_conv2d_fwd", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_fwd, _ptr(x), _ptr(knots), _ptr(wp_f),
                              _ptr(residual), _ptr(y), B, Cin, Cout, H, W, 1 if relu else 0, st), "kmu_kan_conv2d_fwd")
+        if relu:
+            _tap_relu(y)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, knots, spline_w, scaler, wp_b, y if relu else None)
@@ -711,6 +724,8 @@ class BnBlendFn(torch.autograd.Function):
         _lib.check(_call(("bn_blend_fwd", (B, C, HW)), lib.kmu_bn_blend_fwd, _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row),
                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), int(relu), int(training), _ptr(out),
                          _ptr(stats), _ptr(ws), _ptr(nbt), B, C, HW, _stream()), "kmu_bn_blend_fwd")
+        if relu and not has_blend:
+            _tap_relu(out)
         ctx.save_for_backward(t, x, gamma, beta, a_row, stats)
         ctx.cfg = (int(relu), int(training), B, C, HW, S)
         return out
@@ -761,6 +776,8 @@ def _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, relu, traini
     _lib.check(_call(("bn_blend_fwd", (B, C, HW)), lib.kmu_bn_blend_fwd, _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row), _ptr(rm),
                      _ptr(rv), float(momentum), float(eps), int(relu), int(training), _ptr(out), _ptr(stats), _ptr(ws), _ptr(nbt), B, C, HW,
                      _stream()), "kmu_bn_blend_fwd")
+    if relu and a_row is None:
+        _tap_relu(out)
     return out, stats
 
 
@@ -1040,6 +1057,8 @@ class GateMlpFn(torch.autograd.Function):
         _lib.check(_call(("gate_mlp_fwd", (B, I, H, O)), lib.kmu_gate_mlp_fwd, _ptr(p), _ptr(w1c), _ptr(None if b1 is None else _f32c(b1, "b1")),
                          _ptr(w2c), _ptr(None if b2 is None else _f32c(b2, "b2")), _ptr(z1), _ptr(g), B, I, H, O, _ACT1[act1], _ACT2[act2],
                          _stream()), "kmu_gate_mlp_fwd")
+        if act1 == "relu":
+            _tap_relu(z1)
         ctx.save_for_backward(p, w1c, w2c, z1, g)
         ctx.cfg = (_ACT1[act1], _ACT2[act2], b1 is not None, b2 is not None, tuple(w1.shape), tuple(w2.shape))
         return g

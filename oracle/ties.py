@@ -144,6 +144,109 @@ def explain_by_ties(model, x, loss_fn, other, rel=3e-6, tol=1e-4, max_ties=96):
     return report["err_after"] <= tol, report
 
 
+class _MaskReLU(torch.autograd.Function):
+    """relu(x) whose backward uses a given branch mask."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x.clamp(min=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        return g * m, None
+
+
+def collect_gpu_relu_masks(gpu_model, run):
+    """Run `run()` (a forward of the HIP model) and return the ReLU branch masks it took, in execution order: the fused ops
+    report theirs through km_unet_amd.ops.RELU_TAP, plain nn.ReLU modules (DAGEM) through forward hooks."""
+    from km_unet_amd import ops
+    masks, hooks = [], []
+    for mod in gpu_model.modules():
+        if isinstance(mod, nn.ReLU):
+            hooks.append(mod.register_forward_hook(lambda m, i, o: masks.append((o.detach() > 0).cpu())))
+    ops.RELU_TAP = masks
+    try:
+        out = run()
+    finally:
+        ops.RELU_TAP = None
+        for h in hooks:
+            h.remove()
+    return out, masks
+
+
+def grad_with_masks(model, x, loss_fn, masks, params=False):
+    """Gradients of loss_fn(model(x)) with the k-th ReLU call of the forward differentiating through masks[k] (another
+    implementation's branch decisions).  -> (gradients as grad_with_flips, flips) where flips lists, per ReLU call with a
+    disagreement, (module name, number of flipped elements, max |pre-activation| / layer max among them)."""
+    calls, flips, saved = [0], [], []
+    for name, mod in _relus(model):
+        def fwd(inp, name=name):
+            k = calls[0]
+            calls[0] += 1
+            if k >= len(masks) or masks[k].numel() != inp.numel():
+                raise RuntimeError("ReLU call %d (%s, %s) has no matching mask (%s)" % (
+                    k, name, tuple(inp.shape), "none left" if k >= len(masks) else tuple(masks[k].shape)))
+            m = masks[k].reshape(inp.shape)
+            diff = m != (inp.detach() > 0)
+            if bool(diff.any()):
+                p = inp.detach().abs()
+                flips.append((name, int(diff.sum()), (p[diff].max() / p.max()).item()))
+            return _MaskReLU.apply(inp, m)
+        saved.append((mod, mod.forward))
+        mod.forward = fwd
+    try:
+        for q in model.parameters():
+            q.grad = None
+        xr = x.clone().requires_grad_(True)
+        loss_fn(model(xr)).backward()
+    finally:
+        for mod, f in saved:
+            mod.forward = f
+    if calls[0] != len(masks):
+        raise RuntimeError("the oracle made %d ReLU calls, the other implementation reported %d masks" % (calls[0], len(masks)))
+    if not params:
+        return xr.grad.detach(), flips
+    out = {"<input>": xr.grad.detach()}
+    out.update({n: q.grad.detach().clone() for n, q in model.named_parameters() if q.grad is not None})
+    return out, flips
+
+
+def explain_by_masks(model, x, loss_fn, other, masks, tie_rel=2e-4, tol=2e-4):
+    """The direct form of the tie allowance: differentiate the (fp64) oracle through the OTHER implementation's own ReLU
+    branches (`masks`, from collect_gpu_relu_masks) and compare.  ok iff (a) every branch that differs from the oracle's own
+    sits at a pre-activation within `tie_rel` of zero relative to its layer's largest (i.e. within what the other
+    implementation's rounding can move: ~1e-7 for exact-fp32 kernels, ~1e-5 for the split-bf16 matrix-core kernels), and
+    (b) with those branches the gradients agree to `tol` (per tensor, relative to its own maximum, as explain_by_ties).
+    -> (ok, report)"""
+    many = isinstance(other, dict)
+    ref, flips = grad_with_masks(model, x, loss_fn, masks, params=many)
+    if many:
+        keys = [k for k in ref if not k.endswith(".A")]
+        missing = [k for k in keys if k not in other]
+        assert not missing, "gradients missing from the other implementation: %s" % missing[:5]
+        pairs = [(k, ref[k], other[k].detach().cpu().double()) for k in keys]
+    else:
+        pairs = [("<input>", ref, other.detach().cpu().double())]
+    gmax = max(r.abs().max().item() for _, r, _ in pairs)
+    worst = ("", 0.0)
+    for k, r, o in pairs:
+        e = (o - r.double()).abs().max().item() / max(r.abs().max().item(), 1e-6 * gmax, 1e-30)
+        if e > worst[1]:
+            worst = (k, e)
+    far = [f for f in flips if f[2] > tie_rel]
+    report = {"flips": flips, "n_flipped": sum(f[1] for f in flips), "max_flip_rel": max([f[2] for f in flips] + [0.0]),
+              "err": worst[1], "worst": worst[0], "not_ties": far}
+    return (not far) and worst[1] <= tol, report
+
+
+def describe_masks(report):
+    return "%d ReLU branch flip(s) in %d layer(s), furthest pre-activation %.1e of its layer max; gradients with the same branches: %.2e (%s)%s" % (
+        report["n_flipped"], len(report["flips"]), report["max_flip_rel"], report["err"], report["worst"],
+        "; NOT TIES: %s" % report["not_ties"][:3] if report["not_ties"] else "")
+
+
 def describe(report):
     fl = [t for t in report.get("ties", []) if t["flipped"]]
     return "err %.2e -> %.2e after %d flip(s) among %d near-tie ReLU elements%s" % (

@@ -1,9 +1,11 @@
 #!/bin/bash
 O=gpurun_out/s3; mkdir -p $O
 run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
-run 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "bf16x3 or conv3x3 or dagem" > $O/pytest_x3.log 2>&1
-grep -E "^\s+\[|passed|failed|Error" $O/pytest_x3.log | cut -c1-200 | tail -60
-run 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
-tail -25 $O/pytest_gpu.log | cut -c1-250
+run 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -s -k "bf16x3 or conv3x3 or dagem" > $O/pytest_x3.log 2>&1
+grep -E "^\s+\[|passed|failed|Error" $O/pytest_x3.log | cut -c1-200 | tail -50
+run 600 python __graft_entry__.py smoke > $O/smoke.log 2>&1
+grep -E "smoke|Error|assert" $O/smoke.log | cut -c1-300 | tail -8
+run 1000 python -m pytest tests -m gpu -q -s > $O/pytest_gpu.log 2>&1
+grep -E "passed|failed|^FAILED|^ERROR" $O/pytest_gpu.log | tail -20 | cut -c1-250
 run 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
 tail -c 1500 $O/bench.json; grep "^bench:" $O/bench.err | head -14
