@@ -209,62 +209,76 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
     const int NCH = nspl + (Cin + 31) / 32;
     for (int ch = 0; ch < NCH; ++ch) {
         __syncthreads();   // previous chunk's fragment reads done (and the span table visible on the first trip)
+        // this chunk's packed weights (L2-resident): requested before the feature tile is computed, so that their latency
+        // hides under the fill instead of stalling the first MFMA of every tap
+        const bf16x8* wpc = wp + (((size_t)ch * 9) * NT + nt0) * 128 + lane;
+        bf16x8 bh[9][NREP], bl[9][NREP];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+                bh[tap][n] = wpc[((size_t)tap * NT + n) * 128];
+                bl[tap][n] = wpc[((size_t)tap * NT + n) * 128 + 64];
+            }
+        constexpr int ITEMS = (4 * HT + 255) / 256;
         if (MODE == MODE_KAN && ch < nspl) {
-            for (int e = tid; e < 4 * HT; e += 256) {
+            float xv[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {     // all loads first, then the arithmetic
+                const int e = it * 256 + tid;
                 const int q = e / HT, pos = e - q * HT;
                 const int hy = pos / RS, hx = pos - hy * RS;
                 const int gy = ty0 + hy - 1, gx = tx0 + hx - 1, c = ch * 4 + q;
-                float xv = 0.f;   // out-of-image taps see x = 0 -> Phi(0) (reference: F.unfold zero padding)
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) xv = xb[((size_t)c * H + gy) * W + gx];
-                uintx4 vh, vl;
-                spline_bf16x8(xv, tab, kn, u0, inv_h, vh, vl);
-                unsigned char* dst = F + pos * PSTR + q * 16;
-                *reinterpret_cast<uintx4*>(dst) = vh;
-                *reinterpret_cast<uintx4*>(dst + 64) = vl;
+                xv[it] = 0.f;   // out-of-image taps see x = 0 -> Phi(0) (reference: F.unfold zero padding)
+                if (e < 4 * HT && gy >= 0 && gy < H && gx >= 0 && gx < W) xv[it] = xb[((size_t)c * H + gy) * W + gx];
+            }
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int e = it * 256 + tid;
+                if (e < 4 * HT) {
+                    const int q = e / HT, pos = e - q * HT;
+                    uintx4 vh, vl;
+                    spline_bf16x8(xv[it], tab, kn, u0, inv_h, vh, vl);
+                    unsigned char* dst = F + pos * PSTR + q * 16;
+                    *reinterpret_cast<uintx4*>(dst) = vh;
+                    *reinterpret_cast<uintx4*>(dst + 64) = vl;
+                }
             }
         } else {
             const int c0 = (ch - nspl) * 32;
+#pragma unroll 2
             for (int e = tid; e < 4 * HT; e += 256) {
                 const int q = e / HT, pos = e - q * HT;
                 const int hy = pos / RS, hx = pos - hy * RS;
                 const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
                 const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                unsigned hv[8], lv[8];
+                float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = c0 + q * 8 + j;
-                    float v = 0.f;
-                    if (in && c < Cin) {
-                        v = xb[((size_t)c * H + gy) * W + gx];
-                        if (MODE == MODE_KAN) v = silu_f(v);
-                    }
-                    split(v, hv[j], lv[j]);
+                    v[j] = (in && c < Cin) ? xb[((size_t)c * H + gy) * W + gx] : 0.f;
                 }
+                unsigned hv[8], lv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split(MODE == MODE_KAN ? silu_f(v[j]) : v[j], hv[j], lv[j]);
                 unsigned char* dst = F + pos * PSTR + q * 16;
                 *reinterpret_cast<uintx4*>(dst) = uintx4{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
                 *reinterpret_cast<uintx4*>(dst + 64) = uintx4{lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16), lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16)};
             }
         }
         __syncthreads();
-        const bf16x8* wpc = wp + (((size_t)ch * 9) * NT + nt0) * 128 + lane;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = ((tap / 3) * RS + (tap % 3)) * PSTR;
-            bf16x8 bh[NREP], bl[NREP];
-#pragma unroll
-            for (int n = 0; n < NREP; ++n) {
-                bh[n] = wpc[((size_t)tap * NT + n) * 128];
-                bl[n] = wpc[((size_t)tap * NT + n) * 128 + 64];
-            }
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff + 64);
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[tap][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[tap][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[tap][n], acc[m][n], 0, 0, 0);
                 }
             }
         }
