@@ -134,6 +134,16 @@ int kmu_hsmssd_bwd_stage(const float* x, const float* dy, const float* dh, const
                          float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
                          float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage,
                          kmu_stream_t stream);
+/* Backward on the bf16 matrix core with split-bf16 operands (csrc/hsmssd_x3.inc), same three stages and outputs; the
+ * per-tile partial rows follow the x3 tiling: allocate d_w_bcdt_partial / d_w_dw_partial with kmu_hsmssd_bwd_partials_x3 rows
+ * and the workspace with kmu_hsmssd_bwd_ws_bytes_x3 (it also holds the two packed composite-weight sets written by stage 0). */
+size_t kmu_hsmssd_bwd_ws_bytes_x3(int B, int C, int N, int Hs);
+int kmu_hsmssd_bwd_partials_x3(int B, int C, int Hs);
+int kmu_hsmssd_bwd_stage_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
+                            const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
+                            float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
+                            float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage,
+                            kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K3  DySample x2, style 'lp', 4 groups  (DySample_md.py:49-68).

@@ -34,6 +34,9 @@ SIGNATURES = {
     "kmu_hsmssd_fwd_stage_x3": (_I, [_P] * 10 + [_Z] + [_I] * 5 + [_P]),
     "kmu_hsmssd_bwd_stage": (_I, [_P] * 16 + [_Z] + [_I] * 5 + [_P]),
     "kmu_hsmssd_bwd_ws_bytes": (_Z, [_I] * 4),
+    "kmu_hsmssd_bwd_ws_bytes_x3": (_Z, [_I] * 4),
+    "kmu_hsmssd_bwd_partials_x3": (_I, [_I] * 3),
+    "kmu_hsmssd_bwd_stage_x3": (_I, [_P] * 16 + [_Z] + [_I] * 5 + [_P]),
     "kmu_hsmssd_bwd_partials": (_I, [_I] * 3),
     "kmu_hsmssd_gate_partials": (_I, [_I]),
     "kmu_hsmssd_bwd": (_I, [_P] * 16 + [_Z] + [_I] * 4 + [_P]),

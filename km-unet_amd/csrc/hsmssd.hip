@@ -659,6 +659,45 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
 #include "hsmssd_x3.inc"
 #include "hsmssd_bwd.inc"
 
+// backward on the matrix core: ws = [partA | dhpre | delta | composite weights (fragment order) | transposed composite weights]
+template <int C>
+int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                const float* w_out, const float* D, const float* state, float* dx, float* p_bcdt, float* p_dw, float* p_hz,
+                float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st) {
+    int txA, txB;
+    const int TA = tiles_x3<C>(Hs, &txA), TB = tilesB_x3<C>(Hs, &txB);
+    float* partA = ws;
+    float* dhp = partA + (size_t)B * TA * C * NS;
+    float* delta = dhp + (size_t)B * C * NS;
+    unsigned short* wpk = reinterpret_cast<unsigned short*>(delta + (size_t)B * NS);
+    unsigned short* wpkT = wpk + pack_x3_elems(C);
+    const size_t la = lds_passA_x3<C>(), lb = XB<C>::LDS, lg = (size_t)7 * C * GN * sizeof(float);
+    int rc = 0;
+    if (stages & 1) {
+        hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpk);
+        hipLaunchKernelGGL(hsm_packT_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpkT);
+        rc = kmu::launch_status("hsmssd_bwd pack");
+        if (rc) return rc;
+        KMU_MAX_LDS(hsm_bwd_passA_x3<C>, la);
+        hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA);
+        rc = kmu::launch_status("hsmssd_bwd passA (bf16x3)");
+        if (rc) return rc;
+    }
+    if (stages & 2) {
+        hipLaunchKernelGGL(hsm_bwd_gate, dim3(B, NGRP), dim3(256), lg, st, partA, dh, w_hz, w_out, D, state, dhp, delta, p_hz, p_out,
+                           p_D, (float*)nullptr, 0, C, TA);
+        rc = kmu::launch_status("hsmssd_bwd gate");
+        if (rc) return rc;
+    }
+    if (stages & 4) {
+        KMU_MAX_LDS(hsm_bwd_passB_x3<C>, lb);
+        hipLaunchKernelGGL(hsm_bwd_passB_x3<C>, dim3(TB, B), dim3(XB<C>::NW * 64), lb, st, x, dy, w_bcdt, w_dw, (const bf16x8*)wpk,
+                           (const bf16x8*)wpkT, state, dhp, delta, dx, p_bcdt, p_dw, Hs, txB);
+        rc = kmu::launch_status("hsmssd_bwd passB (bf16x3)");
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" size_t kmu_hsmssd_state_elems(int B, int C, int N) { return (size_t)B * ((size_t)2 * N + (size_t)4 * C * N); }
@@ -766,20 +805,40 @@ extern "C" int kmu_hsmssd_bwd_partials(int B, int C, int Hs) {
     int tx;
     return B * tilesB_for(C, Hs, &tx);
 }
+extern "C" size_t kmu_hsmssd_bwd_ws_bytes_x3(int B, int C, int N, int Hs) {
+    int tx;
+    const int TA = C == 16 ? tiles_x3<16>(Hs, &tx) : (C == 32 ? tiles_x3<32>(Hs, &tx) : tiles_x3<64>(Hs, &tx));
+    return ((size_t)B * TA * C * N + (size_t)B * C * N + (size_t)B * N) * sizeof(float) + (pack_x3_elems(C) + packT_x3_elems(C)) * 2;
+}
+extern "C" int kmu_hsmssd_bwd_partials_x3(int B, int C, int Hs) {
+    int tx;
+    return B * (C == 16 ? tilesB_x3<16>(Hs, &tx) : (C == 32 ? tilesB_x3<32>(Hs, &tx) : tilesB_x3<64>(Hs, &tx)));
+}
+
 static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
-                             int Hs, int stages, kmu_stream_t stream) {
+                             int Hs, int stages, kmu_stream_t stream, bool x3 = false) {
     KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial &&
                     d_w_hz_partial && d_w_out_partial && d_D_partial && ws,
                 "hsmssd_bwd: null pointer");
     KMU_REQUIRE(N == NS, "hsmssd_bwd: state_dim=%d unsupported (kernels are built for 64)", N);
     KMU_REQUIRE(C == 16 || C == 32 || C == 64, "hsmssd_bwd: C=%d unsupported (16/32/64)", C);
     KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0, "hsmssd_bwd: bad dims");
-    KMU_REQUIRE(ws_bytes >= kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs), "hsmssd_bwd: workspace too small");
+    KMU_REQUIRE(ws_bytes >= (x3 ? kmu_hsmssd_bwd_ws_bytes_x3(B, C, N, Hs) : kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)), "hsmssd_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* w = (float*)ws;
+    if (x3) {
+        if (C == 16)
+            return bwd_impl_x3<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
+        if (C == 32)
+            return bwd_impl_x3<32>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
+        return bwd_impl_x3<64>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
+    }
     if (C == 16)
         return bwd_impl<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
                             d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
@@ -797,6 +856,15 @@ extern "C" int kmu_hsmssd_bwd(const float* x, const float* dy, const float* dh, 
                               int Hs, kmu_stream_t stream) {
     return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
                              d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 7, stream);
+}
+extern "C" int kmu_hsmssd_bwd_stage_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt,
+                                       const float* w_dw, const float* w_hz, const float* w_out, const float* D,
+                                       const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
+                                       float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, void* ws,
+                                       size_t ws_bytes, int B, int C, int N, int Hs, int stage, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_bwd_stage_x3: stage must be 0 (pack + pass A), 1 (gate) or 2 (pass B)");
+    return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                             d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true);
 }
 extern "C" int kmu_hsmssd_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt,
                                     const float* w_dw, const float* w_hz, const float* w_out, const float* D,

@@ -303,7 +303,8 @@ class HsmssdFn(torch.autograd.Function):
         dev = x.device
         dy = _f32c(dy, "dy") if dy is not None else torch.zeros(B, C, Hs, Hs, device=dev)
         dh = _f32c(dh, "dh") if dh is not None else None
-        P = lib.kmu_hsmssd_bwd_partials(B, C, Hs)
+        x3 = K2_MATH == "bf16x3"
+        P = (lib.kmu_hsmssd_bwd_partials_x3 if x3 else lib.kmu_hsmssd_bwd_partials)(B, C, Hs)
         dx = torch.empty_like(x)
         p_bcdt = torch.empty(P, 3 * N, C, device=dev, dtype=torch.float32)
         p_dw = torch.empty(P, 3 * N, 9, device=dev, dtype=torch.float32)
@@ -311,11 +312,12 @@ class HsmssdFn(torch.autograd.Function):
         p_hz = torch.empty(G, 2 * C, C, device=dev, dtype=torch.float32)
         p_out = torch.empty(G, C, C, device=dev, dtype=torch.float32)
         p_D = torch.empty(G, device=dev, dtype=torch.float32)
-        nbytes = lib.kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)
-        ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
+        nbytes = (lib.kmu_hsmssd_bwd_ws_bytes_x3 if x3 else lib.kmu_hsmssd_bwd_ws_bytes)(B, C, N, Hs)
+        ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
         st = _stream()
+        fn = lib.kmu_hsmssd_bwd_stage_x3 if x3 else lib.kmu_hsmssd_bwd_stage
         for stage, nm in enumerate(("hsmssd_bwd_passA", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
-            _lib.check(_call((nm, (B, C, Hs)), lib.kmu_hsmssd_bwd_stage, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
+            _lib.check(_call((nm + ("_x3" if x3 and stage != 1 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
                              _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
                              _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, st), "kmu_hsmssd_bwd_stage")
         # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd

@@ -244,23 +244,32 @@ def test_k2_softmax_stability_and_shift_invariance():
 @pytest.mark.parametrize("B,C,Hs", [(2, 16, 32), (8, 16, 128), (2, 32, 64), (8, 32, 64), (2, 64, 32), (8, 64, 32), (1, 32, 20), (3, 64, 12),
                                     (1, 16, 37), (1, 16, 480)])
 def test_k2_bf16x3_vs_exact_fp32_kernels(B, C, Hs, monkeypatch):
-    """K2 forward with the projection and the depthwise 3x3 composed into one split-bf16 matrix-core convolution
-    (csrc/hsmssd_x3.inc, the default) against the exact-fp32 kernels (csrc/hsmssd.hip) on the same inputs: y and h to 1e-4 of
-    their magnitude (observed ~1e-5), ragged token grids included, with a sharp softmax (large dt rows)."""
+    """K2 with the projection and the depthwise 3x3 composed into one split-bf16 matrix-core convolution (csrc/hsmssd_x3.inc,
+    the default) against the exact-fp32 kernels (csrc/hsmssd.hip) on the same inputs, forward (y, h) and backward (dx and the
+    five parameter gradients): 1e-4 of each tensor's magnitude forward, 3e-4 backward (observed ~1e-5), ragged token grids
+    included, with a sharp softmax (large dt rows)."""
     ops = _ops()
     gen = torch.Generator().manual_seed(C + Hs)
     N = 64
-    x = torch.randn(B, C, Hs * Hs, generator=gen).to(DEV)
-    w = [(torch.randn(3 * N, C, 1, generator=gen) * 1.5 / C ** 0.5).to(DEV), (torch.randn(3 * N, 1, 3, 3, generator=gen) * 0.5).to(DEV),
-         (torch.randn(2 * C, C, 1, generator=gen) / C ** 0.5).to(DEV), (torch.randn(C, C, 1, generator=gen) / C ** 0.5).to(DEV),
-         torch.zeros(N, device=DEV), torch.ones(1, device=DEV) * 1.2]
-    monkeypatch.setattr(ops, "K2_MATH", "f32")
-    y0, h0 = ops.hsmssd(x, *w)
-    monkeypatch.setattr(ops, "K2_MATH", "bf16x3")
-    y1, h1 = ops.hsmssd(x, *w)
-    ey, eh = rel_err(y1, y0), rel_err(h1, h0)
-    print("  [k2 bf16x3 %s] y %.2e  h %.2e" % ((B, C, Hs), ey, eh))
-    assert ey < 1e-4 and eh < 1e-4
+    x = torch.randn(B, C, Hs * Hs, generator=gen).to(DEV).requires_grad_(True)
+    w = [(torch.randn(3 * N, C, 1, generator=gen) * 1.5 / C ** 0.5).to(DEV).requires_grad_(True),
+         (torch.randn(3 * N, 1, 3, 3, generator=gen) * 0.5).to(DEV).requires_grad_(True),
+         (torch.randn(2 * C, C, 1, generator=gen) / C ** 0.5).to(DEV).requires_grad_(True),
+         (torch.randn(C, C, 1, generator=gen) / C ** 0.5).to(DEV).requires_grad_(True),
+         torch.zeros(N, device=DEV), (torch.ones(1, device=DEV) * 1.2).requires_grad_(True)]
+    gy = torch.randn(B, C, Hs, Hs, generator=gen).to(DEV)
+    gh = (torch.randn(B, C, N, generator=gen) * 0.1).to(DEV)
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        monkeypatch.setattr(ops, "K2_MATH", mode)
+        y, h = ops.hsmssd(x, *w)
+        grads = torch.autograd.grad((y * gy).sum() + (h * gh).sum(), [x, w[0], w[1], w[2], w[3], w[5]])
+        res[mode] = (y.detach(), h.detach()) + tuple(grads)
+    names = ("y", "h", "dx", "d_w_bcdt", "d_w_dw", "d_w_hz", "d_w_out", "d_D")
+    errs = {n: rel_err(a, b) for n, a, b in zip(names, res["bf16x3"], res["f32"])}
+    print("  [k2 bf16x3 %s] " % ((B, C, Hs),) + "  ".join("%s=%.1e" % kv for kv in errs.items()))
+    assert errs["y"] < 1e-4 and errs["h"] < 1e-4
+    assert all(errs[n] < 3e-4 for n in names[2:]), errs
 
 
 @pytest.mark.parametrize("B,C,Hs", [(8, 16, 256), (2, 16, 480)])
