@@ -269,7 +269,9 @@ def test_k2_bf16x3_vs_exact_fp32_kernels(B, C, Hs, monkeypatch):
     errs = {n: rel_err(a, b) for n, a, b in zip(names, res["bf16x3"], res["f32"])}
     print("  [k2 bf16x3 %s] " % ((B, C, Hs),) + "  ".join("%s=%.1e" % kv for kv in errs.items()))
     assert errs["y"] < 1e-4 and errs["h"] < 1e-4
-    assert all(errs[n] < 3e-4 for n in names[2:]), errs
+    # d_D is ONE scalar = a sum over B*C*N products with cancellation: the exact-fp32 kernels themselves sit 4e-4 from the
+    # oracle on it (test_k2_vs_oracle), so it gets the oracle tolerance
+    assert all(errs[n] < (3e-4 if n != "d_D" else 2e-3) for n in names[2:]), errs
 
 
 @pytest.mark.parametrize("B,C,Hs", [(8, 16, 256), (2, 16, 480)])
