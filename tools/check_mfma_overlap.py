@@ -13,6 +13,9 @@ PAT = re.compile(r"v_mfma_\S+\s+([av])\[(\d+):(\d+)\],\s*\S+,\s*\S+,\s*([av])\[(
 
 WR = re.compile(r"^(v_accvgpr_write_b32|v_accvgpr_mov_b32|v_mov_b32_e32|v_mov_b32)\s+([av])(\d+),")
 WINDOW = 8   # wait states hipcc itself leaves (s_nop 7) between a 16x16x4 f32 MFMA and a VALU write to its SrcC
+# The bf16 / f16 16x16x32 MFMA is half as long (16 cycles): where hipcc's hazard recognizer DOES see this WAR it leaves 6 wait
+# states (one MFMA + s_nop 4); only a write closer than that is the unpadded pattern this screen exists for.
+WINDOW_BY_OP = {"v_mfma_f32_16x16x32_bf16": 6, "v_mfma_f32_16x16x32_f16": 6}
 
 
 def scan(asm_text):
@@ -42,7 +45,7 @@ def scan(asm_text):
             fd, d0, d1, fc, c0, c1 = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4), int(m.group(5)), int(m.group(6))
             if fd == fc and (d0, d1) != (c0, c1) and not (d1 < c0 or c1 < d0):
                 hits.append((kernel, ln, s))
-            pending.append((fc, c0, c1, WINDOW, s, (fd, d0, d1)))
+            pending.append((fc, c0, c1, WINDOW_BY_OP.get(s.split()[0], WINDOW), s, (fd, d0, d1)))
     return hits
 
 
