@@ -276,9 +276,14 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff + 64);
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
+                    // (the empty asm keeps the fragments live across the MFMA: vdst must never land on srcA / srcB -- see
+                    //  csrc/hsmssd_x3.inc and tools/check_mfma_overlap.py)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[tap][n], acc[m][n], 0, 0, 0);
+                    asm volatile("" ::"v"(al), "v"(bh[tap][n]));
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[tap][n], acc[m][n], 0, 0, 0);
+                    asm volatile("" ::"v"(ah), "v"(bl[tap][n]));
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[tap][n], acc[m][n], 0, 0, 0);
+                    asm volatile("" ::"v"(ah), "v"(bh[tap][n]));
                 }
             }
         }

@@ -21,6 +21,7 @@
 // small partial buffers reduced by the gate kernels (deterministic, no float atomics).
 // Supported: C in {16,32,64}, N = 64 (KM-UNet hard-wires state_dim=64, KM_UNetV3_SH.py:166).
 #include "common.h"
+#include <stdlib.h>
 
 using kmu::floatx4;
 

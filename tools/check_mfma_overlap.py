@@ -8,6 +8,8 @@ import re
 import subprocess
 import sys
 
+# vdst overlapping srcA / srcB of a multi-pass bf16 / f16 MFMA: the destination is written while the operand is still being read
+PAT_AB = re.compile(r"(v_mfma_f32_16x16x32_(?:bf16|f16)|v_mfma_f32_32x32x16_(?:bf16|f16))\s+([av])\[(\d+):(\d+)\],\s*([av])\[(\d+):(\d+)\],\s*([av])\[(\d+):(\d+)\]")
 PAT = re.compile(r"v_mfma_\S+\s+([av])\[(\d+):(\d+)\],\s*\S+,\s*\S+,\s*([av])\[(\d+):(\d+)\]")
 
 
@@ -40,6 +42,12 @@ def scan(asm_text):
         pending = [(a, b, c, d - states, e, g) for (a, b, c, d, e, g) in pending if d > states]
         if s.startswith(".type") and "@function" in s:
             kernel = s.split()[1].split(",")[0]
+        mab = PAT_AB.search(s)
+        if mab:
+            fd, d0, d1 = mab.group(2), int(mab.group(3)), int(mab.group(4))
+            for (fo, o0, o1) in ((mab.group(5), int(mab.group(6)), int(mab.group(7))), (mab.group(8), int(mab.group(9)), int(mab.group(10)))):
+                if fd == fo and not (d1 < o0 or o1 < d0):
+                    hits.append((kernel, ln, "vdst overlaps srcA/srcB: " + s))
         m = PAT.search(s)
         if m:
             fd, d0, d1, fc, c0, c1 = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4), int(m.group(5)), int(m.group(6))
