@@ -22,6 +22,7 @@
 // Supported: C in {16,32,64}, N = 64 (KM-UNet hard-wires state_dim=64, KM_UNetV3_SH.py:166).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 using kmu::floatx4;
 
@@ -673,6 +674,11 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
     unsigned short* wpk = reinterpret_cast<unsigned short*>(delta + (size_t)B * NS);
     unsigned short* wpkT = wpk + pack_x3_elems(C);
     const size_t la = lds_passA_x3<C>(), lb = XB<C>::LDS, lg = (size_t)7 * C * GN * sizeof(float);
+    // Pass B: the exact-fp32 kernel by default.  The matrix-core pass B (hsm_bwd_passB_x3) is complete and correct for C = 16 and
+    // C = 64, but wrong for C = 32 in a way that follows hipcc's register allocation around its inline-asm MFMAs (DESIGN.md
+    // section 4), and it is not yet faster: opt-in for experiments only (KMU_K2_PASSB=x3).
+    static const bool pb_x3 = getenv("KMU_K2_PASSB") && !strcmp(getenv("KMU_K2_PASSB"), "x3");
+    const bool split_dx = !pb_x3 && passB_split(C, Hs) == 2;      // fp32 pass B at C = 64: two workgroups per tile add into dx
     int rc = 0;
     if (stages & 1) {
         hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpk);
@@ -686,15 +692,25 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
     }
     if (stages & 2) {
         hipLaunchKernelGGL(hsm_bwd_gate, dim3(B, NGRP), dim3(256), lg, st, partA, dh, w_hz, w_out, D, state, dhp, delta, p_hz, p_out,
-                           p_D, (float*)nullptr, 0, C, TA);
+                           p_D, split_dx ? dx : (float*)nullptr, C * Hs * Hs / 4, C, TA);
         rc = kmu::launch_status("hsmssd_bwd gate");
         if (rc) return rc;
     }
     if (stages & 4) {
-        KMU_MAX_LDS(hsm_bwd_passB_x3<C>, lb);
-        hipLaunchKernelGGL(hsm_bwd_passB_x3<C>, dim3(TB, B), dim3(XB<C>::NW * 64), lb, st, x, dy, w_bcdt, w_dw, (const bf16x8*)wpk,
-                           (const bf16x8*)wpkT, state, dhp, delta, dx, p_bcdt, p_dw, Hs, txB);
-        rc = kmu::launch_status("hsmssd_bwd passB (bf16x3)");
+        if (pb_x3) {
+            KMU_MAX_LDS(hsm_bwd_passB_x3<C>, lb);
+            hipLaunchKernelGGL(hsm_bwd_passB_x3<C>, dim3(TB, B), dim3(XB<C>::NW * 64), lb, st, x, dy, w_bcdt, w_dw, (const bf16x8*)wpk,
+                               (const bf16x8*)wpkT, state, dhp, delta, dx, p_bcdt, p_dw, Hs, txB);
+            rc = kmu::launch_status("hsmssd_bwd passB (bf16x3)");
+        } else {
+            int txF;
+            const int TBF = tilesB_for(C, Hs, &txF);
+            const size_t lbf = lds_passB<C>();
+            KMU_MAX_LDS(hsm_bwd_passB<C>, lbf);
+            hipLaunchKernelGGL(hsm_bwd_passB<C>, dim3(TBF, B, passB_split(C, Hs)), dim3(TileForB<C>::NW * 64), lbf, st, x, dy, w_bcdt, w_dw,
+                               state, dhp, delta, dx, p_bcdt, p_dw, Hs, txF);
+            rc = kmu::launch_status("hsmssd_bwd passB");
+        }
     }
     return rc;
 }
@@ -813,6 +829,8 @@ extern "C" size_t kmu_hsmssd_bwd_ws_bytes_x3(int B, int C, int N, int Hs) {
 }
 extern "C" int kmu_hsmssd_bwd_partials_x3(int B, int C, int Hs) {
     int tx;
+    static const bool pb_x3 = getenv("KMU_K2_PASSB") && !strcmp(getenv("KMU_K2_PASSB"), "x3");
+    if (!pb_x3) return B * tilesB_for(C, Hs, &tx);       // pass B on the exact-fp32 kernel (default): its tiling
     return B * (C == 16 ? tilesB_x3<16>(Hs, &tx) : (C == 32 ? tilesB_x3<32>(Hs, &tx) : tilesB_x3<64>(Hs, &tx)));
 }
 
