@@ -666,23 +666,27 @@ template <int C>
 int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
                 const float* w_out, const float* D, const float* state, float* dx, float* p_bcdt, float* p_dw, float* p_hz,
                 float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st) {
-    int txA, txB;
-    const int TA = tiles_x3<C>(Hs, &txA), TB = tilesB_x3<C>(Hs, &txB);
+    int txA;
+    const int TA = tiles_x3<C>(Hs, &txA);
     float* partA = ws;
     float* dhp = partA + (size_t)B * TA * C * NS;
     float* delta = dhp + (size_t)B * C * NS;
     unsigned short* wpk = reinterpret_cast<unsigned short*>(delta + (size_t)B * NS);
+    const size_t la = lds_passA_x3<C>(), lg = (size_t)7 * C * GN * sizeof(float);
+    // Pass B: the exact-fp32 kernel.  The matrix-core pass B (hsm_bwd_passB_x3, csrc/hsmssd_x3.inc) is experimental: see its header.
+#ifdef KMU_EXPERIMENTAL_PASSB_X3
     unsigned short* wpkT = wpk + pack_x3_elems(C);
-    const size_t la = lds_passA_x3<C>(), lb = XB<C>::LDS, lg = (size_t)7 * C * GN * sizeof(float);
-    // Pass B: the exact-fp32 kernel by default.  The matrix-core pass B (hsm_bwd_passB_x3) is complete and correct for C = 16 and
-    // C = 64, but wrong for C = 32 in a way that follows hipcc's register allocation around its inline-asm MFMAs (DESIGN.md
-    // section 4), and it is not yet faster: opt-in for experiments only (KMU_K2_PASSB=x3).
     static const bool pb_x3 = getenv("KMU_K2_PASSB") && !strcmp(getenv("KMU_K2_PASSB"), "x3");
+#else
+    const bool pb_x3 = false;
+#endif
     const bool split_dx = !pb_x3 && passB_split(C, Hs) == 2;      // fp32 pass B at C = 64: two workgroups per tile add into dx
     int rc = 0;
     if (stages & 1) {
         hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpk);
+#ifdef KMU_EXPERIMENTAL_PASSB_X3
         hipLaunchKernelGGL(hsm_packT_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpkT);
+#endif
         rc = kmu::launch_status("hsmssd_bwd pack");
         if (rc) return rc;
         KMU_MAX_LDS(hsm_bwd_passA_x3<C>, la);
@@ -697,12 +701,18 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
         if (rc) return rc;
     }
     if (stages & 4) {
+#ifdef KMU_EXPERIMENTAL_PASSB_X3
         if (pb_x3) {
+            int txB;
+            const int TB = tilesB_x3<C>(Hs, &txB);
+            const size_t lb = XB<C>::LDS;
             KMU_MAX_LDS(hsm_bwd_passB_x3<C>, lb);
             hipLaunchKernelGGL(hsm_bwd_passB_x3<C>, dim3(TB, B), dim3(XB<C>::NW * 64), lb, st, x, dy, w_bcdt, w_dw, (const bf16x8*)wpk,
                                (const bf16x8*)wpkT, state, dhp, delta, dx, p_bcdt, p_dw, Hs, txB);
             rc = kmu::launch_status("hsmssd_bwd passB (bf16x3)");
-        } else {
+        } else
+#endif
+        {
             int txF;
             const int TBF = tilesB_for(C, Hs, &txF);
             const size_t lbf = lds_passB<C>();
@@ -829,9 +839,11 @@ extern "C" size_t kmu_hsmssd_bwd_ws_bytes_x3(int B, int C, int N, int Hs) {
 }
 extern "C" int kmu_hsmssd_bwd_partials_x3(int B, int C, int Hs) {
     int tx;
+#ifdef KMU_EXPERIMENTAL_PASSB_X3
     static const bool pb_x3 = getenv("KMU_K2_PASSB") && !strcmp(getenv("KMU_K2_PASSB"), "x3");
-    if (!pb_x3) return B * tilesB_for(C, Hs, &tx);       // pass B on the exact-fp32 kernel (default): its tiling
-    return B * (C == 16 ? tilesB_x3<16>(Hs, &tx) : (C == 32 ? tilesB_x3<32>(Hs, &tx) : tilesB_x3<64>(Hs, &tx)));
+    if (pb_x3) return B * (C == 16 ? tilesB_x3<16>(Hs, &tx) : (C == 32 ? tilesB_x3<32>(Hs, &tx) : tilesB_x3<64>(Hs, &tx)));
+#endif
+    return B * tilesB_for(C, Hs, &tx);       // pass B runs on the exact-fp32 kernel: its tiling
 }
 
 static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,

@@ -20,8 +20,54 @@ WINDOW = 8   # wait states hipcc itself leaves (s_nop 7) between a 16x16x4 f32 M
 WINDOW_BY_OP = {"v_mfma_f32_16x16x32_bf16": 6, "v_mfma_f32_16x16x32_f16": 6}
 
 
+# A non-MFMA instruction reading an MFMA's result before the matrix core has written it back.  hipcc pads this itself for the
+# builtins (it leaves >= 8 wait states behind a 16x16x32 bf16 MFMA, >= 10 behind the 16x16x4 f32 one) but knows nothing about an
+# MFMA inside inline asm: a register copy it schedules right behind such an asm statement reads stale data (seen in
+# hsm_bwd_passB_x3: `v_mov_b64 v[48:49], v[104:105]` one wait state after the MFMA that writes v[104:107]).
+# thresholds = the smallest distance hipcc itself leaves anywhere in this library's builtin code (8 for both shapes), minus one
+READ_WINDOW = {"v_mfma_f32_16x16x32_bf16": 7, "v_mfma_f32_16x16x32_f16": 7, "v_mfma_f32_16x16x4_f32": 7}
+MF_DST = re.compile(r"^(v_mfma_\S+)\s+([av])\[(\d+):(\d+)\],")
+REG = re.compile(r"\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]")
+STORES = ("global_store", "ds_write", "buffer_store", "flat_store", "scratch_store", "global_atomic", "ds_add")
+
+
+def early_readers(asm_text):
+    hits, kernel, pend = [], "?", []
+    for ln, line in enumerate(asm_text.splitlines(), 1):
+        s = line.strip()
+        if s.startswith(".type") and "@function" in s:
+            kernel, pend = s.split()[1].split(",")[0], []
+            continue
+        if not s or s[0] in ";." or s.endswith(":"):
+            continue
+        s = s.split(";")[0].strip()
+        m = MF_DST.match(s)
+        n = re.match(r"s_nop\s+(\d+)", s)
+        states = int(n.group(1)) + 1 if n else 1
+        if not m and not n and pend:
+            ops = s.split(None, 1)[1] if " " in s else ""
+            parts = [q.strip() for q in ops.split(",")]
+            srcs = parts if s.startswith(STORES) else parts[1:]
+            regs = set()
+            for q in srcs:
+                for r in REG.finditer(q):
+                    if r.group(1):
+                        regs.add((r.group(1), int(r.group(2))))
+                    else:
+                        regs.update((r.group(3), k) for k in range(int(r.group(4)), int(r.group(5)) + 1))
+            for (f, lo, hi, age, need, text) in pend:
+                if age < need and any(ff == f and lo <= k <= hi for ff, k in regs):
+                    hits.append((kernel, ln, "'%s' reads the result of '%s' after %d wait state(s) (needs %d)" % (s, text, age, need)))
+        pend = [(f, lo, hi, age + states, need, t) for (f, lo, hi, age, need, t) in pend if age + states < need]
+        if m and m.group(1) in READ_WINDOW:
+            f, lo, hi = m.group(2), int(m.group(3)), int(m.group(4))
+            pend = [q for q in pend if not (q[0] == f and q[1] == lo and q[2] == hi)]
+            pend.append((f, lo, hi, 0, READ_WINDOW[m.group(1)], s))
+    return hits
+
+
 def scan(asm_text):
-    hits, kernel = [], "?"
+    hits, kernel = early_readers(asm_text), "?"
     lines = asm_text.splitlines()
     pending = []   # (file, lo, hi, remaining, text) SrcC ranges of recently issued MFMAs
     for ln, line in enumerate(lines, 1):

@@ -18,10 +18,13 @@ gy = torch.randn(B, C, Hs, Hs, device=d)
 xk = torch.randn(B, 16, 128, 128, device=d)
 grid = km_unet_amd.KANLinear(144, 16).grid.to(d)
 kw = [torch.randn(16, 144, device=d) * 0.1, torch.randn(16, 144, 8, device=d) * 0.1, torch.randn(16, 144, device=d)]
+xc = torch.randn(B, 64, 128, 128, device=d)
+wc = torch.randn(16, 64, 3, 3, device=d) * 0.05
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     y, h = ops.hsmssd(x, *w)
     y.backward(gy)
     ops.kan_conv2d(xk, grid, *kw)
+    ops.conv3x3(xc, wc, None)
 torch.cuda.synchronize()
 print("done")
 
