@@ -376,10 +376,22 @@ size_t kmu_conv3x3_x3_pack_elems(int kan, int Cin, int Cout);
 int kmu_kan_pack_weights_x3(const float* base_weight, const float* spline_weight, const float* spline_scaler, void* wp,
                             int Cin, int Cout, kmu_stream_t stream);
 int kmu_conv3x3_pack_weights_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream);
+/* input gradient of the same conv (autograd of KM_UNetV3_SH.py:375,430-446,...): dx = conv3x3(dy, W2) with W2[c][o][tap] =
+ * W[o][c][8 - tap]; pack W2 with this call (kmu_conv3x3_x3_pack_elems(0, Cout, Cin) elements), then run
+ * kmu_conv3x3_fwd_x3(dy, wp, NULL, dx, B, Cout, Cin, H, W). */
+int kmu_conv3x3_pack_weights_dgrad_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream);
 int kmu_kan_conv2d_fwd_x3(const float* x, const float* knots, const void* wp, const float* residual, float* y, int B, int Cin,
                           int Cout, int H, int W, int relu, kmu_stream_t stream);
 int kmu_conv3x3_fwd_x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                        kmu_stream_t stream);
+/* K1 input gradient on the matrix core (autograd of KANConv2Dlayers.py:15-37 w.r.t. x; same contract as
+ * kmu_kan_conv2d_bwd_input, dy already masked by the ReLU): G = conv3x3(dy, flipped W') per basis, dX = sum_j dPhi_j(x) G_j.
+ * wpd: kmu_kan_dgrad_x3_pack_elems(Cin, Cout) bf16 elements written by kmu_kan_pack_weights_dgrad_x3. */
+size_t kmu_kan_dgrad_x3_pack_elems(int Cin, int Cout);
+int kmu_kan_pack_weights_dgrad_x3(const float* base_weight, const float* spline_weight, const float* spline_scaler, void* wpd,
+                                  int Cin, int Cout, kmu_stream_t stream);
+int kmu_kan_conv2d_bwd_input_x3(const float* x, const float* dy, const float* knots, const void* wpd, float* dx, int B, int Cin,
+                                int Cout, int H, int W, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Contingency counts of the reference evaluator (metrics.py:45-47 float2int: clip(x,0,1)*scale as uint16; :105-114

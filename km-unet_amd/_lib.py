@@ -87,8 +87,12 @@ SIGNATURES = {
     "kmu_conv3x3_x3_pack_elems": (_Z, [_I, _I, _I]),
     "kmu_kan_pack_weights_x3": (_I, [_P] * 4 + [_I, _I, _P]),
     "kmu_conv3x3_pack_weights_x3": (_I, [_P] * 2 + [_I, _I, _P]),
+    "kmu_conv3x3_pack_weights_dgrad_x3": (_I, [_P] * 2 + [_I, _I, _P]),
     "kmu_kan_conv2d_fwd_x3": (_I, [_P] * 5 + [_I] * 6 + [_P]),
     "kmu_conv3x3_fwd_x3": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "kmu_kan_dgrad_x3_pack_elems": (_Z, [_I, _I]),
+    "kmu_kan_pack_weights_dgrad_x3": (_I, [_P] * 4 + [_I, _I, _P]),
+    "kmu_kan_conv2d_bwd_input_x3": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 

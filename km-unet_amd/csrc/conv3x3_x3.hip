@@ -31,7 +31,7 @@ typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 constexpr int PSTR = 160;        // bytes per halo position: hi[32] | lo[32] | 32 B pad
 constexpr int TABW = 12;         // per-span table: u[i-2..i+3], then the six knot-difference reciprocals of the de Boor triangle
 
-enum Mode { MODE_KAN = 0, MODE_PLAIN = 1 };
+enum Mode { MODE_KAN = 0, MODE_PLAIN = 1, MODE_PLAIN_DGRAD = 2 };   // the last one is a weight-pack mode only
 
 __host__ __device__ inline int n_chunks(int mode, int Cin) {
     return mode == MODE_KAN ? Cin / 4 + (Cin + 31) / 32 : (Cin + 31) / 32;
@@ -68,9 +68,14 @@ __global__ void pack_x3_kernel(const float* __restrict__ w0, const float* __rest
         if (mode == MODE_KAN) {
             if (chunk < nspl) v = kan_wprime(w0, w1, w2, Cin, Cout, o, chunk * 4 + (k >> 3), 1 + (k & 7), tap);
             else v = kan_wprime(w0, w1, w2, Cin, Cout, o, (chunk - nspl) * 32 + k, 0, tap);
-        } else {
+        } else if (mode == MODE_PLAIN) {
             const int c = chunk * 32 + k;
             v = (o < Cout && c < Cin) ? w0[((size_t)o * Cin + c) * 9 + tap] : 0.f;
+        } else {
+            // input-gradient pack of a plain conv: dx = conv3x3(dy, W2), W2[c][o][tap'] = W[o][c][8 - tap'] -- here the kernel's
+            // "Cin" is the layer's Cout (k = layer output channel) and its "Cout" the layer's Cin (n = layer input channel)
+            const int lo = chunk * 32 + k, lc = o;
+            v = (lo < Cin && lc < Cout) ? w0[((size_t)lo * Cout + lc) * 9 + (8 - tap)] : 0.f;
         }
         unsigned hi, lo;
         split(v, hi, lo);
@@ -359,6 +364,198 @@ int dispatch_fwd(const float* x, const float* knots, const void* wp, const float
     return launch_fwd<MODE, 4, 16, 4, 1, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);                    // grid.y = NT
 }
 
+
+// =====================================================================================================================
+// K1 input gradient:  G[pix][c][j] = sum_{o,tap} dY[o][pix - tap + 1] W'[o][c][j][tap]   (matrix core, as the forward on dY)
+//                     dX[pix][c]   = sum_j dPhi_j(x[pix][c]) G[pix][c][j]               (epilogue)
+// N tiles are (basis j, 16 input channels): a lane holds all 9 G_j of ITS channel for 4 pixels, so the epilogue is lane-local.
+// Pack: wpd[(((chunk*9 + tap)*9 + j)*CT + ct)*2 + {hi,lo}][lane][8], k = output channel 32 chunk + 8 (l>>4) + jj, col = channel
+// ct*16 + (l&15), value W'[o][c][j][8 - tap] (the flipped tap turns the transposed convolution into a plain one on dY).
+// =====================================================================================================================
+__global__ void pack_kan_dgrad_x3_kernel(const float* __restrict__ bw, const float* __restrict__ sw, const float* __restrict__ sc,
+                                         unsigned short* __restrict__ wp, int Cin, int Cout, int CT, int NCH) {
+    const size_t total = (size_t)NCH * 9 * 9 * CT * 64 * 8;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int jj = e & 7, lane = (e >> 3) & 63;
+        size_t t = e >> 9;
+        const int ct = t % CT;
+        t /= CT;
+        const int j = t % 9;
+        t /= 9;
+        const int tap = t % 9, chunk = (int)(t / 9);
+        const int o = chunk * 32 + 8 * (lane >> 4) + jj, c = ct * 16 + (lane & 15);
+        const float v = kan_wprime(bw, sw, sc, Cin, Cout, o, c, j, 8 - tap);
+        unsigned hi, lo;
+        split(v, hi, lo);
+        const size_t base = (((((size_t)chunk * 9 + tap) * 9 + j) * CT + ct) * 2) * 512 + lane * 8 + jj;
+        wp[base] = (unsigned short)hi;
+        wp[base + 512] = (unsigned short)lo;
+    }
+}
+
+// dPhi/dx of the 9 features (SiLU', 8 cubic B-spline derivatives): the same span search and triangle as spline_bf16x8;
+// N'_{a,3} = 3 [ N_{a,2}/(U_{a+3}-U_a) - N_{a+1,2}/(U_{a+4}-U_{a+1}) ] (csrc/kan_conv2d.hip)
+__device__ __forceinline__ void kan_dphi(float x, const float* tab, const float* kn, float u0, float inv_h, float (&d)[9]) {
+    const float sg = 1.f / (1.f + __expf(-x));
+    d[0] = sg * (1.f + x * (1.f - sg));
+    int i = (int)floorf((x - u0) * inv_h);
+    i = min(max(i, -1), 11);
+    if (x < kn[i + 3]) --i;
+    else if (x >= kn[i + 4]) ++i;
+    const bool valid = (i >= 0) && (i <= 10) && (x >= kn[3]) && (x < kn[14]);
+    const int ic = min(max(i, 0), 10);
+    const floatx4 ta = *reinterpret_cast<const floatx4*>(tab + ic * TABW);
+    const floatx4 tb = *reinterpret_cast<const floatx4*>(tab + ic * TABW + 4);
+    const floatx4 tc = *reinterpret_cast<const floatx4*>(tab + ic * TABW + 8);
+    const float l1 = x - ta[2], r1 = ta[3] - x, l2 = x - ta[1], r2 = tb[0] - x;
+    const float n0 = r1 * tb[2], n1 = l1 * tb[2];
+    float t = n0 * tb[3];
+    const float m0 = r1 * t;
+    const float sv = l2 * t;
+    t = n1 * tc[0];
+    const float m1 = sv + r2 * t, m2 = l1 * t;
+    const float t0 = m0 * tc[1], t1 = m1 * tc[2], t2 = m2 * tc[3];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int r = a - ic + 3;
+        const float v = (r == 0) ? -t0 : (r == 1) ? (t0 - t1) : (r == 2) ? (t1 - t2) : (r == 3) ? t2 : 0.f;
+        d[1 + a] = valid ? 3.f * v : 0.f;
+    }
+}
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256) void kan_dgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ knots, const bf16x8* __restrict__ wpd,
+                                                           float* __restrict__ dx, int Cin, int Cout, int H, int W, int CT,
+                                                           int tilesX) {
+    using G = Geo<TH, TW>;
+    constexpr int RS = G::RS, HT = G::HT, MF = TH * TW / 16, MREP = MF / 4, SPR = TW / 16;
+    static_assert(MF % 4 == 0, "pixel fragments over 4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* F = smem;
+    float* tab = reinterpret_cast<float*>(smem + G::FBYTES);
+    float* kn = tab + 11 * TABW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty0 = (blockIdx.x / tilesX) * TH, tx0 = (blockIdx.x % tilesX) * TW;
+    const int ct = blockIdx.y, b = blockIdx.z;
+    const int li = lane & 15, lg = lane >> 4;
+
+    load_span_table(knots, tab, kn, tid);
+    const float u0 = knots[0], inv_h = 11.f / (knots[11] - knots[0]);
+
+    floatx4 acc[MREP][9];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[m][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    int aoff[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int seg = wave * MREP + m;
+        aoff[m] = ((seg / SPR) * RS + (seg % SPR) * 16 + li) * PSTR + lg * 16;
+    }
+
+    const float* dyb = dy + (size_t)b * Cout * H * W;
+    const int NCH = (Cout + 31) / 32;
+    for (int ch = 0; ch < NCH; ++ch) {
+        __syncthreads();
+        for (int e = tid; e < 4 * HT; e += 256) {       // dY halo tile, 32 output channels, (hi, lo) bf16
+            const int q = e / HT, pos = e - q * HT;
+            const int hy = pos / RS, hx = pos - hy * RS;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            unsigned hv[8], lv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int o = ch * 32 + q * 8 + j;
+                split((in && o < Cout) ? dyb[((size_t)o * H + gy) * W + gx] : 0.f, hv[j], lv[j]);
+            }
+            unsigned char* dst = F + pos * PSTR + q * 16;
+            *reinterpret_cast<uintx4*>(dst) = uintx4{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
+            *reinterpret_cast<uintx4*>(dst + 64) = uintx4{lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16), lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16)};
+        }
+        __syncthreads();
+        const bf16x8* wpc = wpd + ((size_t)ch * 81 * CT + ct) * 128 + lane;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = ((tap / 3) * RS + (tap % 3)) * PSTR;
+            bf16x8 ah[MREP], al[MREP];
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff);
+                al[m] = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff + 64);
+            }
+            bf16x8 bh[9], bl[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                bh[j] = wpc[((size_t)(tap * 9 + j) * CT) * 128];
+                bl[j] = wpc[((size_t)(tap * 9 + j) * CT) * 128 + 64];
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) {
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[j], acc[m][j], 0, 0, 0);
+                    asm volatile("" ::"v"(al[m]), "v"(bh[j]));
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[j], acc[m][j], 0, 0, 0);
+                    asm volatile("" ::"v"(ah[m]), "v"(bl[j]));
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[j], acc[m][j], 0, 0, 0);
+                    asm volatile("" ::"v"(ah[m]), "v"(bh[j]));
+                }
+        }
+    }
+
+    // epilogue: lane = input channel ct*16 + li, registers = 4 consecutive pixels
+    const int c = ct * 16 + li;
+    const bool vec_ok = (W & 3) == 0;
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int seg = wave * MREP + m;
+        const int gy = ty0 + seg / SPR, px0 = tx0 + (seg % SPR) * 16 + lg * 4;
+        if (c >= Cin || gy >= H || px0 >= W) continue;
+        const size_t idx = (((size_t)b * Cin + c) * H + gy) * W + px0;
+        float xv[4], out[4];
+        if (vec_ok && px0 + 3 < W) {
+            const floatx4 t4 = *reinterpret_cast<const floatx4*>(x + idx);
+            xv[0] = t4[0], xv[1] = t4[1], xv[2] = t4[2], xv[3] = t4[3];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[r] = (px0 + r < W) ? x[idx + r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float d[9];
+            kan_dphi(xv[r], tab, kn, u0, inv_h, d);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sum += d[j] * acc[m][j][r];
+            out[r] = sum;
+        }
+        if (vec_ok && px0 + 3 < W) {
+            *reinterpret_cast<floatx4*>(dx + idx) = floatx4{out[0], out[1], out[2], out[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (px0 + r < W) dx[idx + r] = out[r];
+        }
+    }
+}
+
+template <int TH, int TW>
+int launch_kan_dgrad(const float* x, const float* dy, const float* knots, const void* wpd, float* dx, int B, int Cin, int Cout,
+                     int H, int W, hipStream_t st) {
+    using G = Geo<TH, TW>;
+    const int CT = kmu::cdiv(Cin, 16);
+    const int tilesX = kmu::cdiv(W, TW), tilesY = kmu::cdiv(H, TH);
+    auto kern = kan_dgrad_x3_kernel<TH, TW>;
+    KMU_MAX_LDS(kern, G::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(tilesX * tilesY, CT, B), dim3(256), G::LDS_BYTES, st, x, dy, knots, (const bf16x8*)wpd, dx, Cin, Cout,
+                       H, W, CT, tilesX);
+    return kmu::launch_status("kan_conv2d_bwd_input_x3");
+}
+
 }  // namespace
 
 extern "C" size_t kmu_conv3x3_x3_pack_elems(int kan, int Cin, int Cout) {
@@ -388,6 +585,18 @@ extern "C" int kmu_conv3x3_pack_weights_x3(const float* weight, void* wp, int Ci
     return kmu::launch_status("conv3x3_pack_weights_x3");
 }
 
+extern "C" int kmu_conv3x3_pack_weights_dgrad_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream) {
+    KMU_REQUIRE(weight && wp, "conv3x3_pack_weights_dgrad_x3: null pointer");
+    KMU_REQUIRE(Cin > 0 && Cout > 0, "conv3x3_pack_weights_dgrad_x3: bad dims Cin=%d Cout=%d", Cin, Cout);
+    // the forward kernel then runs with (Cin, Cout) := (Cout, Cin)
+    const int NT = kmu::cdiv(Cin, 16), NCH = n_chunks(MODE_PLAIN, Cout);
+    const size_t n = (size_t)NCH * 9 * NT * 512;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (const float*)nullptr,
+                       (const float*)nullptr, (unsigned short*)wp, (int)MODE_PLAIN_DGRAD, Cout, Cin, NT, NCH);
+    return kmu::launch_status("conv3x3_pack_weights_dgrad_x3");
+}
+
 extern "C" int kmu_kan_conv2d_fwd_x3(const float* x, const float* knots, const void* wp, const float* residual, float* y, int B,
                                      int Cin, int Cout, int H, int W, int relu, kmu_stream_t stream) {
     KMU_REQUIRE(x && knots && wp && y, "kan_conv2d_fwd_x3: null pointer");
@@ -400,4 +609,29 @@ extern "C" int kmu_conv3x3_fwd_x3(const float* x, const void* wp, const float* b
     KMU_REQUIRE(x && wp && y, "conv3x3_fwd_x3: null pointer");
     KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && B <= 65535, "conv3x3_fwd_x3: bad dims");
     return dispatch_fwd<MODE_PLAIN>(x, nullptr, wp, bias, nullptr, y, B, Cin, Cout, H, W, 0, (hipStream_t)stream);
+}
+
+extern "C" size_t kmu_kan_dgrad_x3_pack_elems(int Cin, int Cout) {
+    return (size_t)((Cout + 31) / 32) * 81 * kmu::cdiv(Cin, 16) * 2 * 512;
+}
+
+extern "C" int kmu_kan_pack_weights_dgrad_x3(const float* base_weight, const float* spline_weight, const float* spline_scaler,
+                                             void* wpd, int Cin, int Cout, kmu_stream_t stream) {
+    KMU_REQUIRE(base_weight && spline_weight && spline_scaler && wpd, "kan_pack_weights_dgrad_x3: null pointer");
+    KMU_REQUIRE(Cin > 0 && Cout > 0, "kan_pack_weights_dgrad_x3: bad dims Cin=%d Cout=%d", Cin, Cout);
+    const int CT = kmu::cdiv(Cin, 16), NCH = (Cout + 31) / 32;
+    const size_t n = (size_t)NCH * 81 * CT * 512;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_kan_dgrad_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, base_weight, spline_weight,
+                       spline_scaler, (unsigned short*)wpd, Cin, Cout, CT, NCH);
+    return kmu::launch_status("kan_pack_weights_dgrad_x3");
+}
+
+extern "C" int kmu_kan_conv2d_bwd_input_x3(const float* x, const float* dy, const float* knots, const void* wpd, float* dx, int B,
+                                           int Cin, int Cout, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && dy && knots && wpd && dx, "kan_conv2d_bwd_input_x3: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && B <= 65535, "kan_conv2d_bwd_input_x3: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    if ((long)B * H * W >= 32768 && W >= 32) return launch_kan_dgrad<4, 32>(x, dy, knots, wpd, dx, B, Cin, Cout, H, W, st);
+    return launch_kan_dgrad<4, 16>(x, dy, knots, wpd, dx, B, Cin, Cout, H, W, st);
 }

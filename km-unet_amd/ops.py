@@ -132,7 +132,7 @@ class KanConv2dFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         x3 = K1_MATH == "bf16x3" and uniform and Cin % 4 == 0
         wp_f = None if x3 else torch.empty(lib.kmu_kan_pack_fwd_elems(Cin, Cout), device=x.device, dtype=torch.float32)
-        wp_b = torch.empty(lib.kmu_kan_pack_bwd_elems(Cin, Cout), device=x.device, dtype=torch.float32) if need_bwd else None
+        wp_b = torch.empty(lib.kmu_kan_pack_bwd_elems(Cin, Cout), device=x.device, dtype=torch.float32) if (need_bwd and not x3) else None
         st = _stream()
         if wp_f is not None or wp_b is not None:
             _lib.check(lib.kmu_kan_pack_weights(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wp_f), _ptr(wp_b), Cin, Cout, st),
@@ -153,13 +153,14 @@ class KanConv2dFn(torch.autograd.Function):
             _tap_relu(y)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, knots, spline_w, scaler, wp_b, y if relu else None)
+        ctx.x3 = x3
+        ctx.save_for_backward(x, knots, spline_w, scaler, wp_b, y if relu else None, base_w if x3 else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, knots, spline_w, scaler, wp_b, y = ctx.saved_tensors
+        x, knots, spline_w, scaler, wp_b, y, base_w = ctx.saved_tensors
         dy = _f32c(dy, "dy")
         if ctx.relu:
             dy = dy * (y > 0)
@@ -169,8 +170,15 @@ class KanConv2dFn(torch.autograd.Function):
         dx = d_bw = d_sw = d_sc = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(_call(("kan_conv2d_bwd_input", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_input, _ptr(x), _ptr(dy),
-                             _ptr(knots), _ptr(wp_b), _ptr(dx), B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_input")
+            if ctx.x3:       # matrix core: conv3x3(dy, flipped W') per basis + the dPhi epilogue
+                wpd = torch.empty(lib.kmu_kan_dgrad_x3_pack_elems(Cin, Cout), device=x.device, dtype=torch.bfloat16)
+                _lib.check(lib.kmu_kan_pack_weights_dgrad_x3(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wpd), Cin, Cout, st),
+                           "kmu_kan_pack_weights_dgrad_x3")
+                _lib.check(_call(("kan_conv2d_bwd_input_x3", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_input_x3, _ptr(x), _ptr(dy),
+                                 _ptr(knots), _ptr(wpd), _ptr(dx), B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_input_x3")
+            else:
+                _lib.check(_call(("kan_conv2d_bwd_input", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_input, _ptr(x), _ptr(dy),
+                                 _ptr(knots), _ptr(wp_b), _ptr(dx), B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_input")
         if any(ctx.needs_input_grad[2:5]):
             nbytes = lib.kmu_kan_bwd_ws_bytes(B, Cin, Cout, H, W)
             ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
@@ -212,11 +220,25 @@ class Conv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        lib = _lib.load()
         x, weight = ctx.saved_tensors
         dy = _f32c(dy, "dy")
-        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
-        dx, dw, db = torch.ops.aten.convolution_backward(dy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1],
-                                                         [1, 1], False, [0, 0], 1, mask)
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:       # dx = conv3x3(dy, flipped / transposed weights) on the same matrix-core kernel
+            st = _stream()
+            wp = torch.empty(lib.kmu_conv3x3_x3_pack_elems(0, Cout, Cin), device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.kmu_conv3x3_pack_weights_dgrad_x3(_ptr(weight), _ptr(wp), Cin, Cout, st), "kmu_conv3x3_pack_weights_dgrad_x3")
+            dx = torch.empty_like(x)
+            _lib.check(_call(("conv3x3_dgrad_x3", (B, Cin, Cout, H, W)), lib.kmu_conv3x3_fwd_x3, _ptr(dy), _ptr(wp), None, _ptr(dx),
+                             B, Cout, Cin, H, W, st), "kmu_conv3x3_fwd_x3 (dgrad)")
+        # weight / bias gradients: MIOpen's wrw kernel for now (round 3: the transposed-read contraction of csrc/hsmssd_x3.inc)
+        mask = [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
+        dw = db = None
+        if mask[1] or mask[2]:
+            _, dw, db = torch.ops.aten.convolution_backward(dy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1],
+                                                            False, [0, 0], 1, mask)
         return dx, dw, (db if mask[2] else None)
 
 

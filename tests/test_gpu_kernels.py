@@ -114,6 +114,16 @@ def test_k1_bf16x3_vs_exact_fp32_kernel(B, Cin, Cout, H, W, monkeypatch):
     assert e < 1e-4
     yr = ops.kan_conv2d(x, grid, bw, sw, sc, residual=res, relu=True)
     assert torch.equal(yr, torch.relu(y))
+    # input gradient: matrix-core dgrad (+ dPhi epilogue) vs the exact-fp32 kernel
+    gy = torch.randn(B, Cout, H, W, generator=gen).to(DEV)
+    dxs = {}
+    for mode in ("f32", "bf16x3"):
+        monkeypatch.setattr(ops, "K1_MATH", mode)
+        xr = x.clone().requires_grad_(True)
+        (dxs[mode],) = torch.autograd.grad((ops.kan_conv2d(xr, grid, bw, sw, sc) * gy).sum(), [xr])
+    ed = rel_err(dxs["bf16x3"], dxs["f32"])
+    print("  [k1 bf16x3 %s] dx vs fp32 kernel %.2e" % ((B, Cin, Cout, H, W), ed))
+    assert ed < 1e-4
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(8, 5, 16, 128, 128, True), (2, 64, 32, 64, 64, True), (2, 64, 16, 64, 64, True),
