@@ -392,6 +392,17 @@ int kmu_kan_pack_weights_dgrad_x3(const float* base_weight, const float* spline_
                                   int Cin, int Cout, kmu_stream_t stream);
 int kmu_kan_conv2d_bwd_input_x3(const float* x, const float* dy, const float* knots, const void* wpd, float* dx, int B, int Cin,
                                 int Cout, int H, int W, kmu_stream_t stream);
+/* Weight gradients on the matrix core (autograd of the same layers w.r.t. their parameters): dW'[o][f][tap] = sum_pix
+ * dY[o][pix] F[pix + tap - 1][f], both operands read transposed from (hi, lo) LDS images; ws: kmu_conv3x3_x3_wgrad_ws_bytes.
+ * K1: same outputs as kmu_kan_conv2d_bwd_weights (final gradients of base_weight / spline_weight / spline_scaler).
+ * Plain conv: d_weight [Cout][Cin][3][3] (the bias gradient is a plain sum over dy, left to the caller). */
+size_t kmu_conv3x3_x3_wgrad_ws_bytes(int kan, int B, int Cin, int Cout, int H, int W);
+int kmu_kan_conv2d_bwd_weights_x3(const float* x, const float* dy, const float* knots, const float* spline_weight,
+                                  const float* spline_scaler, float* d_base_weight, float* d_spline_weight,
+                                  float* d_spline_scaler, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int H, int W,
+                                  kmu_stream_t stream);
+int kmu_conv3x3_bwd_weight_x3(const float* x, const float* dy, float* d_weight, void* ws, size_t ws_bytes, int B, int Cin, int Cout,
+                              int H, int W, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Contingency counts of the reference evaluator (metrics.py:45-47 float2int: clip(x,0,1)*scale as uint16; :105-114

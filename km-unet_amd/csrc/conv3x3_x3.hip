@@ -543,6 +543,221 @@ __global__ __launch_bounds__(256) void kan_dgrad_x3_kernel(const float* __restri
     }
 }
 
+
+// =====================================================================================================================
+// weight gradient:  dW'[o][f][tap] = sum_{b,pix} dY[o][pix] * F[pix + tap - 1][f]      (F = Phi(x) for K1, x for a plain conv)
+// MFMA: rows = 16 output channels, columns = 16 features, K = 32 pixels; BOTH operands are read transposed
+// (ds_read_b64_tr_b16) from (hi, lo) images -- dY as [pixel][16 channels], F as the forward kernel's [halo position][32 features]
+// -- so every tap is just a row offset in the F image (the contraction validated in hsm_bwd_passB_x3's phase 2b).
+// grid = (S pixel-tile splits, feature chunks, 16-channel output tiles); a workgroup walks its 4x32-pixel tiles (wave w = the
+// 32-pixel k-step of tile row w) with 2 feature tiles x 9 taps of accumulators in registers, then the 4 waves' sums meet in LDS
+// in a fixed order and ONE slab[(chunk*OT + ot)*S + s][ft][tap][f_local][o_local] goes to HBM (deterministic two-stage sum).
+// =====================================================================================================================
+constexpr int WG_TH = 4, WG_TW = 32, WG_DPS = 96;      // dY image: 16 channels hi (32 B) | lo (32 B) | 32 B pad
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    typedef short shortx4 __attribute__((ext_vector_type(4)));
+    typedef short shortx8 __attribute__((ext_vector_type(8)));
+    const shortx4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) shortx4*)(p0));
+    const shortx4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) shortx4*)(p1));
+    return __builtin_bit_cast(bf16x8, shortx8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ knots, float* __restrict__ slab, int B,
+                                                               int Cin, int Cout, int H, int W, int OT, int S, int tilesX,
+                                                               int tilesY) {
+    using G = Geo<WG_TH, WG_TW>;
+    constexpr int RS = G::RS, HT = G::HT, NPIX = WG_TH * WG_TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* F = smem;
+    float* tab = reinterpret_cast<float*>(smem + G::FBYTES);
+    float* kn = tab + 11 * TABW;
+    unsigned char* DY = smem + G::LDS_BYTES;              // [NPIX][WG_DPS]
+    float* red = reinterpret_cast<float*>(smem);          // aliases F after the main loop: [4 waves][6 tiles][256]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int s = blockIdx.x, ch = blockIdx.y, ot = blockIdx.z;
+
+    float u0 = 0.f, inv_h = 0.f;
+    if (MODE == MODE_KAN) {
+        load_span_table(knots, tab, kn, tid);
+        u0 = knots[0];
+        inv_h = 11.f / (knots[11] - knots[0]);
+    }
+    const int nspl = MODE == MODE_KAN ? Cin / 4 : 0;
+
+    floatx4 acc[2][9];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[ft][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // Mechanism addresses of the transposed reads (block row (li >> 2), columns 4 (li & 3)..): this wave's 32 pixels = tile row
+    // `wave`, lane group lg covers pixels 8 lg + {0..3} and {4..7}
+    const int px0 = 8 * lg + (li >> 2);
+    const int a0 = (wave * WG_TW + px0) * WG_DPS + 8 * (li & 3), a1 = a0 + 4 * WG_DPS;
+    const int f0 = (wave * RS + px0) * PSTR + 8 * (li & 3), f1 = f0 + 4 * PSTR;       // tap (0,0): halo position (wave, px0)
+
+    const int ntiles = B * tilesY * tilesX;
+    for (int tile = s; tile < ntiles; tile += S) {
+        const int b = tile / (tilesY * tilesX), tr = tile % (tilesY * tilesX);
+        const int ty0 = (tr / tilesX) * WG_TH, tx0 = (tr % tilesX) * WG_TW;
+        const float* xb = x + (size_t)b * Cin * H * W;
+        const float* dyb = dy + (size_t)b * Cout * H * W;
+        __syncthreads();       // previous tile's reads done (and the span table visible on the first trip)
+        if (MODE == MODE_KAN && ch < nspl) {
+            for (int e = tid; e < 4 * HT; e += 256) {
+                const int q = e / HT, pos = e - q * HT;
+                const int hy = pos / RS, hx = pos - hy * RS;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1, c = ch * 4 + q;
+                float xv = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) xv = xb[((size_t)c * H + gy) * W + gx];
+                uintx4 vh, vl;
+                spline_bf16x8(xv, tab, kn, u0, inv_h, vh, vl);
+                unsigned char* dst = F + pos * PSTR + q * 16;
+                *reinterpret_cast<uintx4*>(dst) = vh;
+                *reinterpret_cast<uintx4*>(dst + 64) = vl;
+            }
+        } else {
+            const int c0 = (ch - nspl) * 32;
+            for (int e = tid; e < 4 * HT; e += 256) {
+                const int q = e / HT, pos = e - q * HT;
+                const int hy = pos / RS, hx = pos - hy * RS;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                unsigned hv[8], lv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + q * 8 + j;
+                    float v = (in && c < Cin) ? xb[((size_t)c * H + gy) * W + gx] : 0.f;
+                    if (MODE == MODE_KAN) v = silu_f(v);
+                    split(v, hv[j], lv[j]);
+                }
+                unsigned char* dst = F + pos * PSTR + q * 16;
+                *reinterpret_cast<uintx4*>(dst) = uintx4{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
+                *reinterpret_cast<uintx4*>(dst + 64) = uintx4{lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16), lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16)};
+            }
+        }
+        {   // dY tile: 2 x 8 channels of output tile ot at the 128 pixels (zero outside the image)
+            const int q = tid >> 7, pix = tid & 127;
+            const int gy = ty0 + pix / WG_TW, gx = tx0 + pix % WG_TW;
+            const bool in = gy < H && gx < W;
+            unsigned hv[8], lv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int o = ot * 16 + q * 8 + j;
+                split((in && o < Cout) ? dyb[((size_t)o * H + gy) * W + gx] : 0.f, hv[j], lv[j]);
+            }
+            unsigned char* dst = DY + pix * WG_DPS + q * 16;
+            *reinterpret_cast<uintx4*>(dst) = uintx4{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
+            *reinterpret_cast<uintx4*>(dst + 32) = uintx4{lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16), lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16)};
+        }
+        __syncthreads();
+        const bf16x8 ah = tr_pair(DY + a0, DY + a1), al = tr_pair(DY + a0 + 32, DY + a1 + 32);
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int to = ((t / 3) * RS + (t % 3)) * PSTR + ft * 32;
+                const bf16x8 bh = tr_pair(F + f0 + to, F + f1 + to), bl = tr_pair(F + f0 + to + 64, F + f1 + to + 64);
+                acc[ft][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[ft][t], 0, 0, 0);
+                asm volatile("" ::"v"(al), "v"(bh));
+                acc[ft][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[ft][t], 0, 0, 0);
+                asm volatile("" ::"v"(ah), "v"(bl));
+                acc[ft][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[ft][t], 0, 0, 0);
+                asm volatile("" ::"v"(ah), "v"(bh));
+            }
+    }
+
+    // cross-wave sums, 6 accumulator tiles per round through LDS; D[o][f]: lane = feature li, registers = channels 4 lg + r
+    float* out = slab + ((((size_t)ch * OT + ot) * S + s) * 18) * 256;
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int id = round * 6 + k;
+            *reinterpret_cast<floatx4*>(red + ((wave * 6 + k) * 256) + li * 16 + 4 * lg) = acc[id / 9][id % 9];
+        }
+        __syncthreads();
+        for (int e = tid; e < 6 * 64; e += 256) {
+            const int k = e >> 6, v4 = e & 63;
+            floatx4 sum = *reinterpret_cast<const floatx4*>(red + (k * 256) + v4 * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const floatx4*>(red + ((w * 6 + k) * 256) + v4 * 4);
+            *reinterpret_cast<floatx4*>(out + (size_t)(round * 6 + k) * 256 + v4 * 4) = sum;
+        }
+    }
+}
+
+// slab -> parameter gradients.  One thread per (o, c, tap); sums the S splits in a fixed order.
+__global__ void kan_wgrad_x3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ sw, const float* __restrict__ sc,
+                                           float* __restrict__ d_bw, float* __restrict__ d_sw, float* __restrict__ d_sc, int Cin,
+                                           int Cout, int OT, int S) {
+    const int total = Cout * Cin * 9, nspl = Cin / 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e % 9, c = (e / 9) % Cin, o = e / (9 * Cin);
+        const int ot = o >> 4, ol = o & 15;
+        auto fetch = [&](int chunk, int fl) {
+            const float* p = slab + ((((size_t)chunk * OT + ot) * S) * 18 + (fl >> 4) * 9 + tap) * 256 + (fl & 15) * 16 + ol;
+            float a = 0.f;
+            for (int sp = 0; sp < S; ++sp) a += p[(size_t)sp * 18 * 256];
+            return a;
+        };
+        const size_t f = (size_t)o * (Cin * 9) + c * 9 + tap;
+        d_bw[f] = fetch(nspl + c / 32, c % 32);
+        const float scale = sc[f];
+        float dsc = 0.f;
+#pragma unroll 1
+        for (int a = 0; a < 8; ++a) {
+            const float g = fetch(c / 4, (c % 4) * 8 + a);
+            d_sw[f * 8 + a] = g * scale;
+            dsc += g * sw[f * 8 + a];
+        }
+        d_sc[f] = dsc;
+    }
+}
+
+__global__ void conv3x3_wgrad_x3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cin, int Cout, int OT,
+                                               int S) {
+    const int total = Cout * Cin * 9;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e % 9, c = (e / 9) % Cin, o = e / (9 * Cin);
+        const int chunk = c / 32, fl = c % 32;
+        const float* p = slab + ((((size_t)chunk * OT + (o >> 4)) * S) * 18 + (fl >> 4) * 9 + tap) * 256 + (fl & 15) * 16 + (o & 15);
+        float a = 0.f;
+        for (int sp = 0; sp < S; ++sp) a += p[(size_t)sp * 18 * 256];
+        dw[e] = a;       // [Cout][Cin][3][3]
+    }
+}
+
+inline int wgrad_splits(int mode, int B, int Cin, int Cout, int H, int W) {
+    const int nch = n_chunks(mode, Cin), ot = kmu::cdiv(Cout, 16);
+    const int ntiles = B * kmu::cdiv(H, WG_TH) * kmu::cdiv(W, WG_TW);
+    int S = 768 / (nch * ot);
+    if (S > 64) S = 64;
+    if (S > ntiles) S = ntiles;
+    if (S < 1) S = 1;
+    return S;
+}
+
+template <int MODE>
+int launch_wgrad(const float* x, const float* dy, const float* knots, float* slab, int B, int Cin, int Cout, int H, int W,
+                 hipStream_t st) {
+    using G = Geo<WG_TH, WG_TW>;
+    const int NCH = n_chunks(MODE, Cin), OT = kmu::cdiv(Cout, 16), S = wgrad_splits(MODE, B, Cin, Cout, H, W);
+    const int tilesX = kmu::cdiv(W, WG_TW), tilesY = kmu::cdiv(H, WG_TH);
+    const size_t lds = (size_t)G::LDS_BYTES + WG_TH * WG_TW * WG_DPS;
+    auto kern = conv3x3_x3_wgrad_kernel<MODE>;
+    KMU_MAX_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(S, NCH, OT), dim3(256), lds, st, x, dy, knots, slab, B, Cin, Cout, H, W, OT, S, tilesX, tilesY);
+    return kmu::launch_status("conv3x3_x3 wgrad");
+}
+
 template <int TH, int TW>
 int launch_kan_dgrad(const float* x, const float* dy, const float* knots, const void* wpd, float* dx, int B, int Cin, int Cout,
                      int H, int W, hipStream_t st) {
@@ -634,4 +849,41 @@ extern "C" int kmu_kan_conv2d_bwd_input_x3(const float* x, const float* dy, cons
     hipStream_t st = (hipStream_t)stream;
     if ((long)B * H * W >= 32768 && W >= 32) return launch_kan_dgrad<4, 32>(x, dy, knots, wpd, dx, B, Cin, Cout, H, W, st);
     return launch_kan_dgrad<4, 16>(x, dy, knots, wpd, dx, B, Cin, Cout, H, W, st);
+}
+
+extern "C" size_t kmu_conv3x3_x3_wgrad_ws_bytes(int kan, int B, int Cin, int Cout, int H, int W) {
+    const int mode = kan ? MODE_KAN : MODE_PLAIN;
+    return (size_t)n_chunks(mode, Cin) * kmu::cdiv(Cout, 16) * wgrad_splits(mode, B, Cin, Cout, H, W) * 18 * 256 * sizeof(float);
+}
+
+extern "C" int kmu_kan_conv2d_bwd_weights_x3(const float* x, const float* dy, const float* knots, const float* spline_weight,
+                                             const float* spline_scaler, float* d_base_weight, float* d_spline_weight,
+                                             float* d_spline_scaler, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int H, int W,
+                                             kmu_stream_t stream) {
+    KMU_REQUIRE(x && dy && knots && spline_weight && spline_scaler && d_base_weight && d_spline_weight && d_spline_scaler && ws,
+                "kan_conv2d_bwd_weights_x3: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Cin % 4 == 0, "kan_conv2d_bwd_weights_x3: bad dims");
+    KMU_REQUIRE(ws_bytes >= kmu_conv3x3_x3_wgrad_ws_bytes(1, B, Cin, Cout, H, W), "kan_conv2d_bwd_weights_x3: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_wgrad<MODE_KAN>(x, dy, knots, (float*)ws, B, Cin, Cout, H, W, st);
+    if (rc) return rc;
+    const int total = Cout * Cin * 9;
+    hipLaunchKernelGGL(kan_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, spline_weight,
+                       spline_scaler, d_base_weight, d_spline_weight, d_spline_scaler, Cin, Cout, kmu::cdiv(Cout, 16),
+                       wgrad_splits(MODE_KAN, B, Cin, Cout, H, W));
+    return kmu::launch_status("kan_conv2d_bwd_weights_x3 reduce");
+}
+
+extern "C" int kmu_conv3x3_bwd_weight_x3(const float* x, const float* dy, float* d_weight, void* ws, size_t ws_bytes, int B, int Cin,
+                                         int Cout, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && dy && d_weight && ws, "conv3x3_bwd_weight_x3: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_bwd_weight_x3: bad dims");
+    KMU_REQUIRE(ws_bytes >= kmu_conv3x3_x3_wgrad_ws_bytes(0, B, Cin, Cout, H, W), "conv3x3_bwd_weight_x3: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_wgrad<MODE_PLAIN>(x, dy, nullptr, (float*)ws, B, Cin, Cout, H, W, st);
+    if (rc) return rc;
+    const int total = Cout * Cin * 9;
+    hipLaunchKernelGGL(conv3x3_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, d_weight, Cin,
+                       Cout, kmu::cdiv(Cout, 16), wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W));
+    return kmu::launch_status("conv3x3_bwd_weight_x3 reduce");
 }

@@ -51,6 +51,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     const int b = blockIdx.x / bpp, p0 = (blockIdx.x % bpp) * 256 + wave * 64;
     const int n0 = blockIdx.y * 16 * NT;
 
+    // this wave's first x chunk is requested BEFORE the weights are staged: the two round trips (x from HBM, W from L2 + the
+    // barrier) then overlap instead of queueing behind each other in every (short-lived) workgroup
+    const float* xb = x + (size_t)b * K * P + p0 + 4 * ((m >> 2) + 4 * (m & 3));
+    floatx4 xv[4], xn[4];
+    if (p0 < P) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xv[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(4 * q + s) * P);
+    }
     // stage W[n0 .. n0+16NT) x [0, K) -> wl[k][n]
     if (w_sk == 1) {
         for (int e = tid; e < 16 * NT * K; e += 256) {
@@ -66,16 +74,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     __syncthreads();
     if (p0 >= P) return;
 
-    const float* xb = x + (size_t)b * K * P + p0 + 4 * ((m >> 2) + 4 * (m & 3));
     floatx4 acc[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[nt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    floatx4 xv[4], xn[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xv[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(4 * q + s) * P);
     const int nchunk = K / 16;
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk) {

@@ -20,7 +20,10 @@ from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingMod
 
 import os as _os
 
-_BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "0") == "1"   # measured slower (34.1 vs 30.6 ms/step): opt-in only
+# Fork the three direction branches of EnhancedViMBlock onto side HIP streams.  Eagerly (host-bound) this lost in round 1
+# (34.1 vs 30.6 ms/step); inside the captured hipGraph the branches become parallel graph branches and their small kernels
+# overlap: 17.16 vs 17.91 ms/step (round 2, B=8).  On by default; KMU_BRANCH_STREAMS=0 serialises them again.
+_BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") == "1"
 _SIDE = {}
 
 

@@ -180,14 +180,21 @@ class KanConv2dFn(torch.autograd.Function):
                 _lib.check(_call(("kan_conv2d_bwd_input", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_input, _ptr(x), _ptr(dy),
                                  _ptr(knots), _ptr(wp_b), _ptr(dx), B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_input")
         if any(ctx.needs_input_grad[2:5]):
-            nbytes = lib.kmu_kan_bwd_ws_bytes(B, Cin, Cout, H, W)
-            ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
             d_bw = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
             d_sw = torch.empty(Cout, Cin * 9, 8, device=x.device, dtype=torch.float32)
             d_sc = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
-            _lib.check(_call(("kan_conv2d_bwd_weights", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights, _ptr(x), _ptr(dy),
-                             _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
-                             B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights")
+            if ctx.x3:
+                nbytes = lib.kmu_conv3x3_x3_wgrad_ws_bytes(1, B, Cin, Cout, H, W)
+                ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+                _lib.check(_call(("kan_conv2d_bwd_weights_x3", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights_x3, _ptr(x), _ptr(dy),
+                                 _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
+                                 B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights_x3")
+            else:
+                nbytes = lib.kmu_kan_bwd_ws_bytes(B, Cin, Cout, H, W)
+                ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+                _lib.check(_call(("kan_conv2d_bwd_weights", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights, _ptr(x), _ptr(dy),
+                                 _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
+                                 B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights")
         return dx, None, d_bw, d_sw, d_sc, (dy if ctx.has_res else None), None
 
 
@@ -233,12 +240,17 @@ class Conv3x3Fn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.check(_call(("conv3x3_dgrad_x3", (B, Cin, Cout, H, W)), lib.kmu_conv3x3_fwd_x3, _ptr(dy), _ptr(wp), None, _ptr(dx),
                              B, Cout, Cin, H, W, st), "kmu_conv3x3_fwd_x3 (dgrad)")
-        # weight / bias gradients: MIOpen's wrw kernel for now (round 3: the transposed-read contraction of csrc/hsmssd_x3.inc)
-        mask = [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
         dw = db = None
-        if mask[1] or mask[2]:
-            _, dw, db = torch.ops.aten.convolution_backward(dy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1],
-                                                            False, [0, 0], 1, mask)
+        if ctx.needs_input_grad[1]:       # dW[o][c][tap] = sum_pix dy[o][pix] x[c][pix + tap - 1]: transposed-read contraction
+            st = _stream()
+            nbytes = lib.kmu_conv3x3_x3_wgrad_ws_bytes(0, B, Cin, Cout, H, W)
+            ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+            dw = torch.empty_like(weight)
+            _lib.check(_call(("conv3x3_bwd_weight_x3", (B, Cin, Cout, H, W)), lib.kmu_conv3x3_bwd_weight_x3, _ptr(x), _ptr(dy), _ptr(dw),
+                             _ptr(ws), nbytes, B, Cin, Cout, H, W, st), "kmu_conv3x3_bwd_weight_x3")
+        mask = [False, False, ctx.has_bias and ctx.needs_input_grad[2]]
+        if mask[2]:
+            db = dy.sum(dim=(0, 2, 3))
         return dx, dw, (db if mask[2] else None)
 
 

@@ -124,6 +124,15 @@ def test_k1_bf16x3_vs_exact_fp32_kernel(B, Cin, Cout, H, W, monkeypatch):
     ed = rel_err(dxs["bf16x3"], dxs["f32"])
     print("  [k1 bf16x3 %s] dx vs fp32 kernel %.2e" % ((B, Cin, Cout, H, W), ed))
     assert ed < 1e-4
+    # parameter gradients: the transposed-read matrix-core contraction vs the exact-fp32 kernels
+    gs = {}
+    for mode in ("f32", "bf16x3"):
+        monkeypatch.setattr(ops, "K1_MATH", mode)
+        ps = [t.clone().requires_grad_(True) for t in (bw, sw, sc)]
+        gs[mode] = torch.autograd.grad((ops.kan_conv2d(x, grid, *ps) * gy).sum(), ps)
+    ew = [rel_err(a, b) for a, b in zip(gs["bf16x3"], gs["f32"])]
+    print("  [k1 bf16x3 %s] d_base %.2e d_spline %.2e d_scaler %.2e" % ((B, Cin, Cout, H, W), *ew))
+    assert max(ew) < 1e-4
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(8, 5, 16, 128, 128, True), (2, 64, 32, 64, 64, True), (2, 64, 16, 64, 64, True),
