@@ -392,6 +392,17 @@ int kmu_kan_pack_weights_dgrad_x3(const float* base_weight, const float* spline_
                                   int Cin, int Cout, kmu_stream_t stream);
 int kmu_kan_conv2d_bwd_input_x3(const float* x, const float* dy, const float* knots, const void* wpd, float* dx, int B, int Cin,
                                 int Cout, int H, int W, kmu_stream_t stream);
+/* The same three plain-conv calls for K x K / stride 1 / padding K/2, K in {3, 5, 7} (MultiScaleFusion's 5x5 and 7x7 convs,
+ * KM_UNetV3_SH.py:300-306): weight [Cout][Cin][K][K]; dgrad = 1 packs the flipped / transposed weights whose "forward" on dy is
+ * the input gradient (pack size and forward call then take (Cout, Cin) swapped). */
+size_t kmu_conv2d_x3_pack_elems(int Cin, int Cout, int ksize);
+int kmu_conv2d_pack_weights_x3(const float* weight, void* wp, int Cin, int Cout, int ksize, int dgrad, kmu_stream_t stream);
+int kmu_conv2d_fwd_x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ksize,
+                      kmu_stream_t stream);
+size_t kmu_conv2d_x3_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ksize);
+int kmu_conv2d_bwd_weight_x3(const float* x, const float* dy, float* d_weight, void* ws, size_t ws_bytes, int B, int Cin, int Cout,
+                             int H, int W, int ksize, kmu_stream_t stream);
+
 /* Weight gradients on the matrix core (autograd of the same layers w.r.t. their parameters): dW'[o][f][tap] = sum_pix
  * dY[o][pix] F[pix + tap - 1][f], both operands read transposed from (hi, lo) LDS images; ws: kmu_conv3x3_x3_wgrad_ws_bytes.
  * K1: same outputs as kmu_kan_conv2d_bwd_weights (final gradients of base_weight / spline_weight / spline_scaler).

@@ -96,6 +96,11 @@ SIGNATURES = {
     "kmu_conv3x3_x3_wgrad_ws_bytes": (_Z, [_I] * 6),
     "kmu_kan_conv2d_bwd_weights_x3": (_I, [_P] * 9 + [_Z] + [_I] * 5 + [_P]),
     "kmu_conv3x3_bwd_weight_x3": (_I, [_P] * 4 + [_Z] + [_I] * 5 + [_P]),
+    "kmu_conv2d_x3_pack_elems": (_Z, [_I, _I, _I]),
+    "kmu_conv2d_pack_weights_x3": (_I, [_P] * 2 + [_I] * 4 + [_P]),
+    "kmu_conv2d_fwd_x3": (_I, [_P] * 4 + [_I] * 6 + [_P]),
+    "kmu_conv2d_x3_wgrad_ws_bytes": (_Z, [_I] * 6),
+    "kmu_conv2d_bwd_weight_x3": (_I, [_P] * 4 + [_Z] + [_I] * 6 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 

@@ -54,15 +54,15 @@ __device__ __forceinline__ float kan_wprime(const float* bw, const float* sw, co
 }
 
 __global__ void pack_x3_kernel(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
-                               unsigned short* __restrict__ wp, int mode, int Cin, int Cout, int NT, int NCH) {
-    const size_t total = (size_t)NCH * 9 * NT * 64 * 8;
+                               unsigned short* __restrict__ wp, int mode, int Cin, int Cout, int NT, int NCH, int T) {
+    const size_t total = (size_t)NCH * T * NT * 64 * 8;
     const int nspl = mode == MODE_KAN ? Cin / 4 : 0;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int j = e & 7, lane = (e >> 3) & 63;
         size_t t = e >> 9;
         const int nt = t % NT;
         t /= NT;
-        const int tap = t % 9, chunk = (int)(t / 9);
+        const int tap = t % T, chunk = (int)(t / T);
         const int k = 8 * (lane >> 4) + j, o = nt * 16 + (lane & 15);
         float v;
         if (mode == MODE_KAN) {
@@ -70,16 +70,16 @@ __global__ void pack_x3_kernel(const float* __restrict__ w0, const float* __rest
             else v = kan_wprime(w0, w1, w2, Cin, Cout, o, (chunk - nspl) * 32 + k, 0, tap);
         } else if (mode == MODE_PLAIN) {
             const int c = chunk * 32 + k;
-            v = (o < Cout && c < Cin) ? w0[((size_t)o * Cin + c) * 9 + tap] : 0.f;
+            v = (o < Cout && c < Cin) ? w0[((size_t)o * Cin + c) * T + tap] : 0.f;
         } else {
             // input-gradient pack of a plain conv: dx = conv3x3(dy, W2), W2[c][o][tap'] = W[o][c][8 - tap'] -- here the kernel's
             // "Cin" is the layer's Cout (k = layer output channel) and its "Cout" the layer's Cin (n = layer input channel)
             const int lo = chunk * 32 + k, lc = o;
-            v = (lo < Cin && lc < Cout) ? w0[((size_t)lo * Cout + lc) * 9 + (8 - tap)] : 0.f;
+            v = (lo < Cin && lc < Cout) ? w0[((size_t)lo * Cout + lc) * T + (T - 1 - tap)] : 0.f;
         }
         unsigned hi, lo;
         split(v, hi, lo);
-        const size_t base = ((((size_t)chunk * 9 + tap) * NT + nt) * 2) * 512 + lane * 8 + j;
+        const size_t base = ((((size_t)chunk * T + tap) * NT + nt) * 2) * 512 + lane * 8 + j;
         wp[base] = (unsigned short)hi;
         wp[base + 512] = (unsigned short)lo;
     }
@@ -158,9 +158,9 @@ __device__ __forceinline__ void spline_bf16x8(float x, const float* tab, const f
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
-template <int TH, int TW>
+template <int TH, int TW, int KSZ = 3>
 struct Geo {
-    static constexpr int RS = TW + 2, HT = (TH + 2) * RS;
+    static constexpr int R = KSZ / 2, RS = TW + 2 * R, HT = (TH + 2 * R) * RS;
     static constexpr int FBYTES = HT * PSTR;
     static constexpr int LDS_BYTES = FBYTES + (11 * TABW + 32) * 4;
 };
@@ -168,13 +168,14 @@ struct Geo {
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <int MODE, int TH, int TW, int WM, int WN, int NREP>
+template <int MODE, int KSZ, int TH, int TW, int WM, int WN, int NREP>
 __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ knots,
                                                              const bf16x8* __restrict__ wp, const float* __restrict__ bias,
                                                              const float* __restrict__ residual, float* __restrict__ y, int Cin,
                                                              int Cout, int H, int W, int NT, int tilesX, int relu) {
-    using G = Geo<TH, TW>;
-    constexpr int RS = G::RS, HT = G::HT, MF = TH * TW / 16, MREP = MF / WM, SPR = TW / 16;
+    using G = Geo<TH, TW, KSZ>;
+    constexpr int RS = G::RS, HT = G::HT, MF = TH * TW / 16, MREP = MF / WM, SPR = TW / 16, R = G::R, T = KSZ * KSZ;
+    static_assert(MODE != MODE_KAN || KSZ == 3, "KANConv2d is 3x3");
     static_assert(WM * WN == 4 && MF % WM == 0, "4 waves over the pixel fragments / channel tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* F = smem;
@@ -216,15 +217,18 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
         __syncthreads();   // previous chunk's fragment reads done (and the span table visible on the first trip)
         // this chunk's packed weights (L2-resident): requested before the feature tile is computed, so that their latency
         // hides under the fill instead of stalling the first MFMA of every tap
-        const bf16x8* wpc = wp + (((size_t)ch * 9) * NT + nt0) * 128 + lane;
-        bf16x8 bh[9][NREP], bl[9][NREP];
+        const bf16x8* wpc = wp + (((size_t)ch * T) * NT + nt0) * 128 + lane;
+        constexpr int TPRE = KSZ == 3 ? 9 : 1;          // 3x3: all taps' fragments ahead of the fill; 5x5 / 7x7: per tap below
+        bf16x8 bh[TPRE][NREP], bl[TPRE][NREP];
+        if (KSZ == 3) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+            for (int tap = 0; tap < TPRE; ++tap)
 #pragma unroll
-            for (int n = 0; n < NREP; ++n) {
-                bh[tap][n] = wpc[((size_t)tap * NT + n) * 128];
-                bl[tap][n] = wpc[((size_t)tap * NT + n) * 128 + 64];
-            }
+                for (int n = 0; n < NREP; ++n) {
+                    bh[tap][n] = wpc[((size_t)tap * NT + n) * 128];
+                    bl[tap][n] = wpc[((size_t)tap * NT + n) * 128 + 64];
+                }
+        }
         constexpr int ITEMS = (4 * HT + 255) / 256;
         if (MODE == MODE_KAN && ch < nspl) {
             float xv[ITEMS];
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
                 const int e = it * 256 + tid;
                 const int q = e / HT, pos = e - q * HT;
                 const int hy = pos / RS, hx = pos - hy * RS;
-                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1, c = ch * 4 + q;
+                const int gy = ty0 + hy - R, gx = tx0 + hx - R, c = ch * 4 + q;
                 xv[it] = 0.f;   // out-of-image taps see x = 0 -> Phi(0) (reference: F.unfold zero padding)
                 if (e < 4 * HT && gy >= 0 && gy < H && gx >= 0 && gx < W) xv[it] = xb[((size_t)c * H + gy) * W + gx];
             }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
             for (int e = tid; e < 4 * HT; e += 256) {
                 const int q = e / HT, pos = e - q * HT;
                 const int hy = pos / RS, hx = pos - hy * RS;
-                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                const int gy = ty0 + hy - R, gx = tx0 + hx - R;
                 const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
                 float v[8];
 #pragma unroll
@@ -273,8 +277,16 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
         }
         __syncthreads();
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * RS + (tap % 3)) * PSTR;
+        for (int tap = 0; tap < T; ++tap) {
+            const int toff = ((tap / KSZ) * RS + (tap % KSZ)) * PSTR;
+            const int tb = KSZ == 3 ? tap : 0;
+            if (KSZ != 3) {
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    bh[0][n] = wpc[((size_t)tap * NT + n) * 128];
+                    bl[0][n] = wpc[((size_t)tap * NT + n) * 128 + 64];
+                }
+            }
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(F + aoff[m] + toff);
@@ -283,12 +295,12 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
                 for (int n = 0; n < NREP; ++n) {
                     // (the empty asm keeps the fragments live across the MFMA: vdst must never land on srcA / srcB -- see
                     //  csrc/hsmssd_x3.inc and tools/check_mfma_overlap.py)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[tap][n], acc[m][n], 0, 0, 0);
-                    asm volatile("" ::"v"(al), "v"(bh[tap][n]));
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[tap][n], acc[m][n], 0, 0, 0);
-                    asm volatile("" ::"v"(ah), "v"(bl[tap][n]));
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[tap][n], acc[m][n], 0, 0, 0);
-                    asm volatile("" ::"v"(ah), "v"(bh[tap][n]));
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[tb][n], acc[m][n], 0, 0, 0);
+                    asm volatile("" ::"v"(al), "v"(bh[tb][n]));
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[tb][n], acc[m][n], 0, 0, 0);
+                    asm volatile("" ::"v"(ah), "v"(bl[tb][n]));
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[tb][n], acc[m][n], 0, 0, 0);
+                    asm volatile("" ::"v"(ah), "v"(bh[tb][n]));
                 }
             }
         }
@@ -325,14 +337,14 @@ __global__ __launch_bounds__(256) void conv3x3_x3_fwd_kernel(const float* __rest
     }
 }
 
-template <int MODE, int TH, int TW, int WM, int WN, int NREP>
+template <int MODE, int TH, int TW, int WM, int WN, int NREP, int KSZ = 3>
 int launch_fwd(const float* x, const float* knots, const void* wp, const float* bias, const float* residual, float* y, int B,
                int Cin, int Cout, int H, int W, int relu, hipStream_t st) {
-    using G = Geo<TH, TW>;
+    using G = Geo<TH, TW, KSZ>;
     const int NT = kmu::cdiv(Cout, 16);
     const int tilesX = kmu::cdiv(W, TW), tilesY = kmu::cdiv(H, TH);
     dim3 grid(tilesX * tilesY, NT / (WN * NREP), B);
-    auto kern = conv3x3_x3_fwd_kernel<MODE, TH, TW, WM, WN, NREP>;
+    auto kern = conv3x3_x3_fwd_kernel<MODE, KSZ, TH, TW, WM, WN, NREP>;
     KMU_MAX_LDS(kern, G::LDS_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, st, x, knots, (const bf16x8*)wp, bias, residual, y, Cin, Cout, H, W, NT,
                        tilesX, relu);
@@ -563,13 +575,14 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigne
     return __builtin_bit_cast(bf16x8, shortx8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
 }
 
-template <int MODE>
+template <int MODE, int KSZ>
 __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ knots, float* __restrict__ slab, int B,
                                                                int Cin, int Cout, int H, int W, int OT, int S, int tilesX,
                                                                int tilesY) {
-    using G = Geo<WG_TH, WG_TW>;
-    constexpr int RS = G::RS, HT = G::HT, NPIX = WG_TH * WG_TW;
+    using G = Geo<WG_TH, WG_TW, KSZ>;
+    constexpr int RS = G::RS, HT = G::HT, NPIX = WG_TH * WG_TW, R = G::R, T = KSZ * KSZ, TG = (T + 8) / 9;
+    static_assert(MODE != MODE_KAN || KSZ == 3, "KANConv2d is 3x3");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* F = smem;
     float* tab = reinterpret_cast<float*>(smem + G::FBYTES);
@@ -580,7 +593,8 @@ __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int s = blockIdx.x, ch = blockIdx.y, ot = blockIdx.z;
+    // blockIdx.y = (feature chunk, group of 9 taps): a KxK kernel's K*K tap accumulators are dealt 9 per workgroup
+    const int s = blockIdx.x, ch = blockIdx.y / TG, tg = blockIdx.y % TG, ot = blockIdx.z;
 
     float u0 = 0.f, inv_h = 0.f;
     if (MODE == MODE_KAN) {
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __re
             for (int e = tid; e < 4 * HT; e += 256) {
                 const int q = e / HT, pos = e - q * HT;
                 const int hy = pos / RS, hx = pos - hy * RS;
-                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1, c = ch * 4 + q;
+                const int gy = ty0 + hy - R, gx = tx0 + hx - R, c = ch * 4 + q;
                 float xv = 0.f;
                 if (gy >= 0 && gy < H && gx >= 0 && gx < W) xv = xb[((size_t)c * H + gy) * W + gx];
                 uintx4 vh, vl;
@@ -627,7 +641,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __re
             for (int e = tid; e < 4 * HT; e += 256) {
                 const int q = e / HT, pos = e - q * HT;
                 const int hy = pos / RS, hx = pos - hy * RS;
-                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                const int gy = ty0 + hy - R, gx = tx0 + hx - R;
                 const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
                 unsigned hv[8], lv[8];
 #pragma unroll
@@ -662,7 +676,9 @@ __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __re
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int to = ((t / 3) * RS + (t % 3)) * PSTR + ft * 32;
+                const int tap = tg * 9 + t;
+                if (tap >= T) continue;          // (workgroup-uniform) the last tap group of a 5x5 / 7x7 kernel is partial
+                const int to = ((tap / KSZ) * RS + (tap % KSZ)) * PSTR + ft * 32;
                 const bf16x8 bh = tr_pair(F + f0 + to, F + f1 + to), bl = tr_pair(F + f0 + to + 64, F + f1 + to + 64);
                 acc[ft][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[ft][t], 0, 0, 0);
                 asm volatile("" ::"v"(al), "v"(bh));
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __re
     }
 
     // cross-wave sums, 6 accumulator tiles per round through LDS; D[o][f]: lane = feature li, registers = channels 4 lg + r
-    float* out = slab + ((((size_t)ch * OT + ot) * S + s) * 18) * 256;
+    float* out = slab + (((((size_t)ch * TG + tg) * OT + ot) * S + s) * 18) * 256;
 #pragma unroll
     for (int round = 0; round < 3; ++round) {
         __syncthreads();
@@ -723,20 +739,20 @@ __global__ void kan_wgrad_x3_reduce_kernel(const float* __restrict__ slab, const
 }
 
 __global__ void conv3x3_wgrad_x3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cin, int Cout, int OT,
-                                               int S) {
-    const int total = Cout * Cin * 9;
+                                               int S, int T) {
+    const int total = Cout * Cin * T, TG = (T + 8) / 9;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int tap = e % 9, c = (e / 9) % Cin, o = e / (9 * Cin);
+        const int tap = e % T, c = (e / T) % Cin, o = e / (T * Cin);
         const int chunk = c / 32, fl = c % 32;
-        const float* p = slab + ((((size_t)chunk * OT + (o >> 4)) * S) * 18 + (fl >> 4) * 9 + tap) * 256 + (fl & 15) * 16 + (o & 15);
+        const float* p = slab + (((((size_t)chunk * TG + tap / 9) * OT + (o >> 4)) * S) * 18 + (fl >> 4) * 9 + tap % 9) * 256 + (fl & 15) * 16 + (o & 15);
         float a = 0.f;
         for (int sp = 0; sp < S; ++sp) a += p[(size_t)sp * 18 * 256];
-        dw[e] = a;       // [Cout][Cin][3][3]
+        dw[e] = a;       // [Cout][Cin][K][K]
     }
 }
 
-inline int wgrad_splits(int mode, int B, int Cin, int Cout, int H, int W) {
-    const int nch = n_chunks(mode, Cin), ot = kmu::cdiv(Cout, 16);
+inline int wgrad_splits(int mode, int B, int Cin, int Cout, int H, int W, int ksize = 3) {
+    const int nch = n_chunks(mode, Cin) * ((ksize * ksize + 8) / 9), ot = kmu::cdiv(Cout, 16);
     const int ntiles = B * kmu::cdiv(H, WG_TH) * kmu::cdiv(W, WG_TW);
     int S = 768 / (nch * ot);
     if (S > 64) S = 64;
@@ -745,14 +761,14 @@ inline int wgrad_splits(int mode, int B, int Cin, int Cout, int H, int W) {
     return S;
 }
 
-template <int MODE>
+template <int MODE, int KSZ = 3>
 int launch_wgrad(const float* x, const float* dy, const float* knots, float* slab, int B, int Cin, int Cout, int H, int W,
                  hipStream_t st) {
-    using G = Geo<WG_TH, WG_TW>;
-    const int NCH = n_chunks(MODE, Cin), OT = kmu::cdiv(Cout, 16), S = wgrad_splits(MODE, B, Cin, Cout, H, W);
+    using G = Geo<WG_TH, WG_TW, KSZ>;
+    const int NCH = n_chunks(MODE, Cin) * ((KSZ * KSZ + 8) / 9), OT = kmu::cdiv(Cout, 16), S = wgrad_splits(MODE, B, Cin, Cout, H, W, KSZ);
     const int tilesX = kmu::cdiv(W, WG_TW), tilesY = kmu::cdiv(H, WG_TH);
     const size_t lds = (size_t)G::LDS_BYTES + WG_TH * WG_TW * WG_DPS;
-    auto kern = conv3x3_x3_wgrad_kernel<MODE>;
+    auto kern = conv3x3_x3_wgrad_kernel<MODE, KSZ>;
     KMU_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(S, NCH, OT), dim3(256), lds, st, x, dy, knots, slab, B, Cin, Cout, H, W, OT, S, tilesX, tilesY);
     return kmu::launch_status("conv3x3_x3 wgrad");
@@ -771,6 +787,16 @@ int launch_kan_dgrad(const float* x, const float* dy, const float* knots, const 
     return kmu::launch_status("kan_conv2d_bwd_input_x3");
 }
 
+// 5x5 / 7x7 (MultiScaleFusion, KM_UNetV3_SH.py:300-306): small tiles (the halo grows), per-tap weight fragments
+template <int KSZ>
+int dispatch_fwd_k(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                   hipStream_t st) {
+    const int NT = kmu::cdiv(Cout, 16);
+    if (NT % 4 == 0) return launch_fwd<MODE_PLAIN, 4, 16, 1, 4, 1, KSZ>(x, nullptr, wp, bias, nullptr, y, B, Cin, Cout, H, W, 0, st);
+    if (NT % 2 == 0) return launch_fwd<MODE_PLAIN, 4, 16, 2, 2, 1, KSZ>(x, nullptr, wp, bias, nullptr, y, B, Cin, Cout, H, W, 0, st);
+    return launch_fwd<MODE_PLAIN, 4, 16, 4, 1, 1, KSZ>(x, nullptr, wp, bias, nullptr, y, B, Cin, Cout, H, W, 0, st);
+}
+
 }  // namespace
 
 extern "C" size_t kmu_conv3x3_x3_pack_elems(int kan, int Cin, int Cout) {
@@ -785,31 +811,37 @@ extern "C" int kmu_kan_pack_weights_x3(const float* base_weight, const float* sp
     const size_t n = (size_t)NCH * 9 * NT * 512;
     const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, base_weight, spline_weight, spline_scaler,
-                       (unsigned short*)wp, (int)MODE_KAN, Cin, Cout, NT, NCH);
+                       (unsigned short*)wp, (int)MODE_KAN, Cin, Cout, NT, NCH, 9);
     return kmu::launch_status("kan_pack_weights_x3");
 }
 
-extern "C" int kmu_conv3x3_pack_weights_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream) {
-    KMU_REQUIRE(weight && wp, "conv3x3_pack_weights_x3: null pointer");
-    KMU_REQUIRE(Cin > 0 && Cout > 0, "conv3x3_pack_weights_x3: bad dims Cin=%d Cout=%d", Cin, Cout);
-    const int NT = kmu::cdiv(Cout, 16), NCH = n_chunks(MODE_PLAIN, Cin);
-    const size_t n = (size_t)NCH * 9 * NT * 512;
+static bool ksize_ok(int k) { return k == 3 || k == 5 || k == 7; }
+
+extern "C" size_t kmu_conv2d_x3_pack_elems(int Cin, int Cout, int ksize) {
+    return (size_t)n_chunks(MODE_PLAIN, Cin) * ksize * ksize * kmu::cdiv(Cout, 16) * 2 * 512;
+}
+
+// dgrad = 0: forward pack of weight [Cout][Cin][K][K]; dgrad = 1: the flipped / transposed pack whose "forward" is the input
+// gradient (run kmu_conv2d_fwd_x3(dy, wp, NULL, dx, B, Cout, Cin, H, W, ksize) with it; kmu_conv2d_x3_pack_elems(Cout, Cin, ksize))
+extern "C" int kmu_conv2d_pack_weights_x3(const float* weight, void* wp, int Cin, int Cout, int ksize, int dgrad, kmu_stream_t stream) {
+    KMU_REQUIRE(weight && wp, "conv2d_pack_weights_x3: null pointer");
+    KMU_REQUIRE(Cin > 0 && Cout > 0 && ksize_ok(ksize), "conv2d_pack_weights_x3: bad dims Cin=%d Cout=%d k=%d (3/5/7)", Cin, Cout, ksize);
+    const int T = ksize * ksize;
+    const int kin = dgrad ? Cout : Cin, kout = dgrad ? Cin : Cout;       // the kernel's view
+    const int NT = kmu::cdiv(kout, 16), NCH = n_chunks(MODE_PLAIN, kin);
+    const size_t n = (size_t)NCH * T * NT * 512;
     const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (const float*)nullptr,
-                       (const float*)nullptr, (unsigned short*)wp, (int)MODE_PLAIN, Cin, Cout, NT, NCH);
-    return kmu::launch_status("conv3x3_pack_weights_x3");
+                       (const float*)nullptr, (unsigned short*)wp, (int)(dgrad ? MODE_PLAIN_DGRAD : MODE_PLAIN), kin, kout, NT, NCH, T);
+    return kmu::launch_status("conv2d_pack_weights_x3");
+}
+
+extern "C" int kmu_conv3x3_pack_weights_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream) {
+    return kmu_conv2d_pack_weights_x3(weight, wp, Cin, Cout, 3, 0, stream);
 }
 
 extern "C" int kmu_conv3x3_pack_weights_dgrad_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream) {
-    KMU_REQUIRE(weight && wp, "conv3x3_pack_weights_dgrad_x3: null pointer");
-    KMU_REQUIRE(Cin > 0 && Cout > 0, "conv3x3_pack_weights_dgrad_x3: bad dims Cin=%d Cout=%d", Cin, Cout);
-    // the forward kernel then runs with (Cin, Cout) := (Cout, Cin)
-    const int NT = kmu::cdiv(Cin, 16), NCH = n_chunks(MODE_PLAIN, Cout);
-    const size_t n = (size_t)NCH * 9 * NT * 512;
-    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (const float*)nullptr,
-                       (const float*)nullptr, (unsigned short*)wp, (int)MODE_PLAIN_DGRAD, Cout, Cin, NT, NCH);
-    return kmu::launch_status("conv3x3_pack_weights_dgrad_x3");
+    return kmu_conv2d_pack_weights_x3(weight, wp, Cin, Cout, 3, 1, stream);
 }
 
 extern "C" int kmu_kan_conv2d_fwd_x3(const float* x, const float* knots, const void* wp, const float* residual, float* y, int B,
@@ -819,11 +851,19 @@ extern "C" int kmu_kan_conv2d_fwd_x3(const float* x, const float* knots, const v
     return dispatch_fwd<MODE_KAN>(x, knots, wp, nullptr, residual, y, B, Cin, Cout, H, W, relu, (hipStream_t)stream);
 }
 
+extern "C" int kmu_conv2d_fwd_x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                                 int ksize, kmu_stream_t stream) {
+    KMU_REQUIRE(x && wp && y, "conv2d_fwd_x3: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && B <= 65535 && ksize_ok(ksize), "conv2d_fwd_x3: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3) return dispatch_fwd<MODE_PLAIN>(x, nullptr, wp, bias, nullptr, y, B, Cin, Cout, H, W, 0, st);
+    if (ksize == 5) return dispatch_fwd_k<5>(x, wp, bias, y, B, Cin, Cout, H, W, st);
+    return dispatch_fwd_k<7>(x, wp, bias, y, B, Cin, Cout, H, W, st);
+}
+
 extern "C" int kmu_conv3x3_fwd_x3(const float* x, const void* wp, const float* bias, float* y, int B, int Cin, int Cout, int H,
                                   int W, kmu_stream_t stream) {
-    KMU_REQUIRE(x && wp && y, "conv3x3_fwd_x3: null pointer");
-    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && B <= 65535, "conv3x3_fwd_x3: bad dims");
-    return dispatch_fwd<MODE_PLAIN>(x, nullptr, wp, bias, nullptr, y, B, Cin, Cout, H, W, 0, (hipStream_t)stream);
+    return kmu_conv2d_fwd_x3(x, wp, bias, y, B, Cin, Cout, H, W, 3, stream);
 }
 
 extern "C" size_t kmu_kan_dgrad_x3_pack_elems(int Cin, int Cout) {
@@ -874,16 +914,28 @@ extern "C" int kmu_kan_conv2d_bwd_weights_x3(const float* x, const float* dy, co
     return kmu::launch_status("kan_conv2d_bwd_weights_x3 reduce");
 }
 
+extern "C" size_t kmu_conv2d_x3_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {
+    return (size_t)n_chunks(MODE_PLAIN, Cin) * ((ksize * ksize + 8) / 9) * kmu::cdiv(Cout, 16) *
+           wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W, ksize) * 18 * 256 * sizeof(float);
+}
+
+extern "C" int kmu_conv2d_bwd_weight_x3(const float* x, const float* dy, float* d_weight, void* ws, size_t ws_bytes, int B, int Cin,
+                                        int Cout, int H, int W, int ksize, kmu_stream_t stream) {
+    KMU_REQUIRE(x && dy && d_weight && ws, "conv2d_bwd_weight_x3: null pointer");
+    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && ksize_ok(ksize), "conv2d_bwd_weight_x3: bad dims");
+    KMU_REQUIRE(ws_bytes >= kmu_conv2d_x3_wgrad_ws_bytes(B, Cin, Cout, H, W, ksize), "conv2d_bwd_weight_x3: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ksize == 3   ? launch_wgrad<MODE_PLAIN, 3>(x, dy, nullptr, (float*)ws, B, Cin, Cout, H, W, st)
+             : ksize == 5 ? launch_wgrad<MODE_PLAIN, 5>(x, dy, nullptr, (float*)ws, B, Cin, Cout, H, W, st)
+                          : launch_wgrad<MODE_PLAIN, 7>(x, dy, nullptr, (float*)ws, B, Cin, Cout, H, W, st);
+    if (rc) return rc;
+    const int total = Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(conv3x3_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, d_weight, Cin,
+                       Cout, kmu::cdiv(Cout, 16), wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W, ksize), ksize * ksize);
+    return kmu::launch_status("conv2d_bwd_weight_x3 reduce");
+}
+
 extern "C" int kmu_conv3x3_bwd_weight_x3(const float* x, const float* dy, float* d_weight, void* ws, size_t ws_bytes, int B, int Cin,
                                          int Cout, int H, int W, kmu_stream_t stream) {
-    KMU_REQUIRE(x && dy && d_weight && ws, "conv3x3_bwd_weight_x3: null pointer");
-    KMU_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_bwd_weight_x3: bad dims");
-    KMU_REQUIRE(ws_bytes >= kmu_conv3x3_x3_wgrad_ws_bytes(0, B, Cin, Cout, H, W), "conv3x3_bwd_weight_x3: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    int rc = launch_wgrad<MODE_PLAIN>(x, dy, nullptr, (float*)ws, B, Cin, Cout, H, W, st);
-    if (rc) return rc;
-    const int total = Cout * Cin * 9;
-    hipLaunchKernelGGL(conv3x3_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, d_weight, Cin,
-                       Cout, kmu::cdiv(Cout, 16), wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W));
-    return kmu::launch_status("conv3x3_bwd_weight_x3 reduce");
+    return kmu_conv2d_bwd_weight_x3(x, dy, d_weight, ws, ws_bytes, B, Cin, Cout, H, W, 3, stream);
 }

@@ -39,12 +39,14 @@ def conv1x1(x, conv, gelu_in=False):
 
 
 def conv3x3(x, conv):
-    """A plain nn.Conv2d: 3x3 / stride 1 / padding 1 / dense ones run on the split-bf16 matrix-core kernel
-    (csrc/conv3x3_x3.hip; MIOpen served them with NCHW<->NHWC transposes around an implicit GEMM chosen by a timing search);
-    any other geometry (the 5x5 / 7x7 convs of MultiScaleFusion) stays on MIOpen.  KMU_GLUE_TORCH=conv3x3 keeps MIOpen."""
-    if ("conv3x3" not in _TORCH_GLUE and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1):
-        return ops.conv3x3(x, conv.weight, conv.bias)
+    """A plain nn.Conv2d: dense K x K / stride 1 / padding K//2 with K in {3, 5, 7} -- every such conv of the model, incl.
+    MultiScaleFusion's 5x5 / 7x7 -- runs forward and backward on the split-bf16 matrix-core kernels (csrc/conv3x3_x3.hip;
+    MIOpen served them with NCHW<->NHWC transposes around an implicit GEMM chosen by a timing search).  KMU_GLUE_TORCH=conv3x3
+    keeps MIOpen."""
+    k = conv.kernel_size[0]
+    if ("conv3x3" not in _TORCH_GLUE and x.is_cuda and conv.kernel_size in ((3, 3), (5, 5), (7, 7)) and conv.stride == (1, 1)
+            and conv.padding == (k // 2, k // 2) and conv.dilation == (1, 1) and conv.groups == 1):
+        return ops.conv_kxk(x, conv.weight, conv.bias)
     return conv(x)
 
 

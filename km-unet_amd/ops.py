@@ -202,9 +202,10 @@ def kan_conv2d(x, grid, base_weight, spline_weight, spline_scaler, residual=None
     return KanConv2dFn.apply(x, grid, base_weight, spline_weight, spline_scaler, residual, relu)
 
 
-class Conv3x3Fn(torch.autograd.Function):
-    """nn.Conv2d(Cin, Cout, 3, stride 1, padding 1)(x) on the split-bf16 matrix-core kernel (csrc/conv3x3_x3.hip):
-    KM_UNetV3_SH.py:375 (conv_f), :430-446 (dec2[1], dec3[1], dec3[3]), :300-306 (MultiScaleFusion), DAGEM_md.py:43."""
+class ConvKxKFn(torch.autograd.Function):
+    """nn.Conv2d(Cin, Cout, K, stride 1, padding K//2)(x), K in {3, 5, 7}, forward / input gradient / weight gradient on the
+    split-bf16 matrix-core kernels (csrc/conv3x3_x3.hip): KM_UNetV3_SH.py:375 (conv_f), :430-446 (dec2[1], dec3[1], dec3[3]),
+    :300-306 (MultiScaleFusion 3x3 / 5x5 / 7x7), DAGEM_md.py:43 (offset_conv)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -212,15 +213,15 @@ class Conv3x3Fn(torch.autograd.Function):
         x, weight = _f32c(x, "x"), _f32c(weight, "weight")
         bias = _f32c(bias, "bias") if bias is not None else None
         B, Cin, H, W = x.shape
-        Cout = weight.shape[0]
-        if tuple(weight.shape) != (Cout, Cin, 3, 3):
-            raise RuntimeError("conv3x3: weight %s does not match Cin=%d, 3x3" % (tuple(weight.shape), Cin))
+        Cout, K = weight.shape[0], weight.shape[-1]
+        if tuple(weight.shape) != (Cout, Cin, K, K) or K not in (3, 5, 7):
+            raise RuntimeError("conv_kxk: weight %s does not match Cin=%d and a 3x3 / 5x5 / 7x7 kernel" % (tuple(weight.shape), Cin))
         st = _stream()
-        wp = torch.empty(lib.kmu_conv3x3_x3_pack_elems(0, Cin, Cout), device=x.device, dtype=torch.bfloat16)
-        _lib.check(lib.kmu_conv3x3_pack_weights_x3(_ptr(weight), _ptr(wp), Cin, Cout, st), "kmu_conv3x3_pack_weights_x3")
+        wp = torch.empty(lib.kmu_conv2d_x3_pack_elems(Cin, Cout, K), device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.kmu_conv2d_pack_weights_x3(_ptr(weight), _ptr(wp), Cin, Cout, K, 0, st), "kmu_conv2d_pack_weights_x3")
         y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
-        _lib.check(_call(("conv3x3_fwd_x3", (B, Cin, Cout, H, W)), lib.kmu_conv3x3_fwd_x3, _ptr(x), _ptr(wp), _ptr(bias), _ptr(y),
-                         B, Cin, Cout, H, W, st), "kmu_conv3x3_fwd_x3")
+        _lib.check(_call(("conv%dx%d_fwd_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_fwd_x3, _ptr(x), _ptr(wp), _ptr(bias), _ptr(y),
+                         B, Cin, Cout, H, W, K, st), "kmu_conv2d_fwd_x3")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -231,31 +232,31 @@ class Conv3x3Fn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = _f32c(dy, "dy")
         B, Cin, H, W = x.shape
-        Cout = weight.shape[0]
-        dx = None
-        if ctx.needs_input_grad[0]:       # dx = conv3x3(dy, flipped / transposed weights) on the same matrix-core kernel
-            st = _stream()
-            wp = torch.empty(lib.kmu_conv3x3_x3_pack_elems(0, Cout, Cin), device=x.device, dtype=torch.bfloat16)
-            _lib.check(lib.kmu_conv3x3_pack_weights_dgrad_x3(_ptr(weight), _ptr(wp), Cin, Cout, st), "kmu_conv3x3_pack_weights_dgrad_x3")
+        Cout, K = weight.shape[0], weight.shape[-1]
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:       # dx = conv(dy, flipped / transposed weights) on the same kernel
+            wp = torch.empty(lib.kmu_conv2d_x3_pack_elems(Cout, Cin, K), device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.kmu_conv2d_pack_weights_x3(_ptr(weight), _ptr(wp), Cin, Cout, K, 1, st), "kmu_conv2d_pack_weights_x3 (dgrad)")
             dx = torch.empty_like(x)
-            _lib.check(_call(("conv3x3_dgrad_x3", (B, Cin, Cout, H, W)), lib.kmu_conv3x3_fwd_x3, _ptr(dy), _ptr(wp), None, _ptr(dx),
-                             B, Cout, Cin, H, W, st), "kmu_conv3x3_fwd_x3 (dgrad)")
-        dw = db = None
-        if ctx.needs_input_grad[1]:       # dW[o][c][tap] = sum_pix dy[o][pix] x[c][pix + tap - 1]: transposed-read contraction
-            st = _stream()
-            nbytes = lib.kmu_conv3x3_x3_wgrad_ws_bytes(0, B, Cin, Cout, H, W)
+            _lib.check(_call(("conv%dx%d_dgrad_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_fwd_x3, _ptr(dy), _ptr(wp), None, _ptr(dx),
+                             B, Cout, Cin, H, W, K, st), "kmu_conv2d_fwd_x3 (dgrad)")
+        if ctx.needs_input_grad[1]:       # dW[o][c][tap] = sum_pix dy[o][pix] x[c][pix + tap - K//2]: transposed-read contraction
+            nbytes = lib.kmu_conv2d_x3_wgrad_ws_bytes(B, Cin, Cout, H, W, K)
             ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
             dw = torch.empty_like(weight)
-            _lib.check(_call(("conv3x3_bwd_weight_x3", (B, Cin, Cout, H, W)), lib.kmu_conv3x3_bwd_weight_x3, _ptr(x), _ptr(dy), _ptr(dw),
-                             _ptr(ws), nbytes, B, Cin, Cout, H, W, st), "kmu_conv3x3_bwd_weight_x3")
-        mask = [False, False, ctx.has_bias and ctx.needs_input_grad[2]]
-        if mask[2]:
+            _lib.check(_call(("conv%dx%d_bwd_weight_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_bwd_weight_x3, _ptr(x), _ptr(dy),
+                             _ptr(dw), _ptr(ws), nbytes, B, Cin, Cout, H, W, K, st), "kmu_conv2d_bwd_weight_x3")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
-        return dx, dw, (db if mask[2] else None)
+        return dx, dw, db
 
 
-def conv3x3(x, weight, bias=None):
-    return Conv3x3Fn.apply(x, weight, bias)
+def conv_kxk(x, weight, bias=None):
+    return ConvKxKFn.apply(x, weight, bias)
+
+
+conv3x3 = conv_kxk
 
 
 # ------------------------------------------------------------------------------------------ K2

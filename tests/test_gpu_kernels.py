@@ -135,20 +135,22 @@ def test_k1_bf16x3_vs_exact_fp32_kernel(B, Cin, Cout, H, W, monkeypatch):
     assert max(ew) < 1e-4
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(8, 5, 16, 128, 128, True), (2, 64, 32, 64, 64, True), (2, 64, 16, 64, 64, True),
-                                                  (1, 16, 5, 37, 29, True), (2, 64, 18, 16, 16, True), (2, 32, 32, 8, 8, False),
-                                                  (3, 16, 32, 20, 12, True), (1, 40, 70, 9, 9, True)])
-def test_conv3x3_vs_torch_cpu(B, Cin, Cout, H, W, bias):
-    """Plain 3x3 / pad 1 convolution (conv_f, dec2 / dec3, MultiScaleFusion, DAGEM.offset_conv shapes and ragged ones) on
-    the split-bf16 kernel vs F.conv2d in fp64 on the CPU, forward and backward."""
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias,K", [(8, 5, 16, 128, 128, True, 3), (2, 64, 32, 64, 64, True, 3), (2, 64, 16, 64, 64, True, 3),
+                                                    (1, 16, 5, 37, 29, True, 3), (2, 64, 18, 16, 16, True, 3), (2, 32, 32, 8, 8, False, 3),
+                                                    (3, 16, 32, 20, 12, True, 3), (1, 40, 70, 9, 9, True, 3),
+                                                    (8, 32, 32, 64, 64, True, 5), (8, 32, 32, 32, 32, True, 7), (2, 32, 32, 64, 64, True, 7),
+                                                    (1, 20, 24, 13, 9, True, 5), (2, 8, 16, 6, 40, False, 7)])
+def test_conv3x3_vs_torch_cpu(B, Cin, Cout, H, W, bias, K):
+    """Plain K x K / pad K//2 convolution (conv_f, dec2 / dec3, MultiScaleFusion's 3x3 / 5x5 / 7x7, DAGEM.offset_conv shapes
+    and ragged ones) on the split-bf16 kernels vs F.conv2d in fp64 on the CPU, forward and backward."""
     import torch.nn.functional as F
     ops = _ops()
     gen = torch.Generator().manual_seed(Cin * 7 + Cout)
     x = torch.randn(B, Cin, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=gen, dtype=torch.float64) / (3 * Cin ** 0.5)).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, K, K, generator=gen, dtype=torch.float64) / (K * Cin ** 0.5)).requires_grad_(True)
     b = torch.randn(Cout, generator=gen, dtype=torch.float64).requires_grad_(True) if bias else None
     gy = torch.randn(B, Cout, H, W, generator=gen, dtype=torch.float64)
-    yo = F.conv2d(x, w, b, padding=1)
+    yo = F.conv2d(x, w, b, padding=K // 2)
     yo.backward(gy)
     xd, wd = x.detach().float().to(DEV).requires_grad_(True), w.detach().float().to(DEV).requires_grad_(True)
     bd = b.detach().float().to(DEV).requires_grad_(True) if bias else None
@@ -157,7 +159,7 @@ def test_conv3x3_vs_torch_cpu(B, Cin, Cout, H, W, bias):
     errs = {"y": rel_err(y, yo), "dx": rel_err(xd.grad, x.grad), "dw": rel_err(wd.grad, w.grad)}
     if bias:
         errs["db"] = rel_err(bd.grad, b.grad)
-    _report("conv3x3 %s" % ((B, Cin, Cout, H, W),), **errs)
+    _report("conv%dx%d %s" % (K, K, (B, Cin, Cout, H, W)), **errs)
     assert errs["y"] < 1e-4
 
 
