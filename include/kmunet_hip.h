@@ -416,6 +416,13 @@ int kmu_conv3x3_bwd_weight_x3(const float* x, const float* dy, float* d_weight, 
                               int H, int W, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True) between the encoder pyramid levels
+ * (KM_UNetV3_SH.py:487-492, 503-507) and its exact adjoint in gather form (deterministic, no atomics).
+ * ------------------------------------------------------------------------------------ */
+int kmu_resize_bilinear_ac_fwd(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, kmu_stream_t stream);
+int kmu_resize_bilinear_ac_bwd(const float* gy, float* dx, int B, int C, int Hi, int Wi, int Ho, int Wo, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Contingency counts of the reference evaluator (metrics.py:45-47 float2int: clip(x,0,1)*scale as uint16; :105-114
  * _cal_frame; :220-288 pools TP/FN/FP/TN over all frames before forming CSI / POD / FAR / HSS): one pass over
  * pred / target [n] (16-byte aligned), counts [n_thresholds][3] = {TP, FN, FP} as 64-bit integers ADDED to the

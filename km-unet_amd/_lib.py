@@ -101,6 +101,8 @@ SIGNATURES = {
     "kmu_conv2d_fwd_x3": (_I, [_P] * 4 + [_I] * 6 + [_P]),
     "kmu_conv2d_x3_wgrad_ws_bytes": (_Z, [_I] * 6),
     "kmu_conv2d_bwd_weight_x3": (_I, [_P] * 4 + [_Z] + [_I] * 6 + [_P]),
+    "kmu_resize_bilinear_ac_fwd": (_I, [_P] * 2 + [_I] * 6 + [_P]),
+    "kmu_resize_bilinear_ac_bwd": (_I, [_P] * 2 + [_I] * 6 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 

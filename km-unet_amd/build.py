@@ -36,6 +36,7 @@ SOURCES = [
     ("hybrid_loss.hip", []),
     ("contingency.hip", []),
     ("conv3x3_x3.hip", []),
+    ("resize.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

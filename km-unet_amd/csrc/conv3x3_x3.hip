@@ -710,6 +710,24 @@ __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __re
     }
 }
 
+// stage 1 of the slab reduction: out[g][18][256] = sum_s slab[g][s][18][256] (fixed order, coalesced 1-KB rows; one workgroup
+// per accumulator tile).  The unpack kernels below then run on the summed tiles (S = 1): as one kernel each they took 96 / 22 us
+// (every thread walking 9 x S strided values), in two stages ~10.
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int S) {
+    const int g = blockIdx.x / 18, t = blockIdx.x % 18;
+    const float* p = slab + (((size_t)g * S) * 18 + t) * 256 + threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int sp = 0;
+    for (; sp + 3 < S; sp += 4) {
+        a0 += p[(size_t)sp * 18 * 256];
+        a1 += p[(size_t)(sp + 1) * 18 * 256];
+        a2 += p[(size_t)(sp + 2) * 18 * 256];
+        a3 += p[(size_t)(sp + 3) * 18 * 256];
+    }
+    for (; sp < S; ++sp) a0 += p[(size_t)sp * 18 * 256];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = (a0 + a1) + (a2 + a3);
+}
+
 // slab -> parameter gradients.  One thread per (o, c, tap); sums the S splits in a fixed order.
 __global__ void kan_wgrad_x3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ sw, const float* __restrict__ sc,
                                            float* __restrict__ d_bw, float* __restrict__ d_sw, float* __restrict__ d_sc, int Cin,
@@ -893,7 +911,7 @@ extern "C" int kmu_kan_conv2d_bwd_input_x3(const float* x, const float* dy, cons
 
 extern "C" size_t kmu_conv3x3_x3_wgrad_ws_bytes(int kan, int B, int Cin, int Cout, int H, int W) {
     const int mode = kan ? MODE_KAN : MODE_PLAIN;
-    return (size_t)n_chunks(mode, Cin) * kmu::cdiv(Cout, 16) * wgrad_splits(mode, B, Cin, Cout, H, W) * 18 * 256 * sizeof(float);
+    return (size_t)n_chunks(mode, Cin) * kmu::cdiv(Cout, 16) * (wgrad_splits(mode, B, Cin, Cout, H, W) + 1) * 18 * 256 * sizeof(float);
 }
 
 extern "C" int kmu_kan_conv2d_bwd_weights_x3(const float* x, const float* dy, const float* knots, const float* spline_weight,
@@ -907,16 +925,17 @@ extern "C" int kmu_kan_conv2d_bwd_weights_x3(const float* x, const float* dy, co
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_wgrad<MODE_KAN>(x, dy, knots, (float*)ws, B, Cin, Cout, H, W, st);
     if (rc) return rc;
-    const int total = Cout * Cin * 9;
-    hipLaunchKernelGGL(kan_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, spline_weight,
-                       spline_scaler, d_base_weight, d_spline_weight, d_spline_scaler, Cin, Cout, kmu::cdiv(Cout, 16),
-                       wgrad_splits(MODE_KAN, B, Cin, Cout, H, W));
+    const int total = Cout * Cin * 9, S = wgrad_splits(MODE_KAN, B, Cin, Cout, H, W), NG = n_chunks(MODE_KAN, Cin) * kmu::cdiv(Cout, 16);
+    float* sum = (float*)ws + (size_t)NG * S * 18 * 256;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(NG * 18), dim3(256), 0, st, (const float*)ws, sum, S);
+    hipLaunchKernelGGL(kan_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)sum, spline_weight,
+                       spline_scaler, d_base_weight, d_spline_weight, d_spline_scaler, Cin, Cout, kmu::cdiv(Cout, 16), 1);
     return kmu::launch_status("kan_conv2d_bwd_weights_x3 reduce");
 }
 
 extern "C" size_t kmu_conv2d_x3_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {
     return (size_t)n_chunks(MODE_PLAIN, Cin) * ((ksize * ksize + 8) / 9) * kmu::cdiv(Cout, 16) *
-           wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W, ksize) * 18 * 256 * sizeof(float);
+           (wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W, ksize) + 1) * 18 * 256 * sizeof(float);
 }
 
 extern "C" int kmu_conv2d_bwd_weight_x3(const float* x, const float* dy, float* d_weight, void* ws, size_t ws_bytes, int B, int Cin,
@@ -929,9 +948,12 @@ extern "C" int kmu_conv2d_bwd_weight_x3(const float* x, const float* dy, float* 
              : ksize == 5 ? launch_wgrad<MODE_PLAIN, 5>(x, dy, nullptr, (float*)ws, B, Cin, Cout, H, W, st)
                           : launch_wgrad<MODE_PLAIN, 7>(x, dy, nullptr, (float*)ws, B, Cin, Cout, H, W, st);
     if (rc) return rc;
-    const int total = Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(conv3x3_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, d_weight, Cin,
-                       Cout, kmu::cdiv(Cout, 16), wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W, ksize), ksize * ksize);
+    const int total = Cout * Cin * ksize * ksize, S = wgrad_splits(MODE_PLAIN, B, Cin, Cout, H, W, ksize);
+    const int NG = n_chunks(MODE_PLAIN, Cin) * ((ksize * ksize + 8) / 9) * kmu::cdiv(Cout, 16);
+    float* sum = (float*)ws + (size_t)NG * S * 18 * 256;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(NG * 18), dim3(256), 0, st, (const float*)ws, sum, S);
+    hipLaunchKernelGGL(conv3x3_wgrad_x3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)sum, d_weight, Cin,
+                       Cout, kmu::cdiv(Cout, 16), 1, ksize * ksize);
     return kmu::launch_status("conv2d_bwd_weight_x3 reduce");
 }
 

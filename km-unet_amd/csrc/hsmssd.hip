@@ -262,18 +262,34 @@ __global__ __launch_bounds__(256) void hsm_fwd_gate(const float* __restrict__ pa
     const float* pms = part_ms + (size_t)b * T * 2 * NS;
     const float* pac = part_acc + (size_t)b * T * NS * C;
     float* st = state + (size_t)b * state_stride(C);
-    if (tid < GN) {
-        const int n = nb + tid;
-        float M = -INFINITY;
-#pragma unroll 8
-        for (int t = 0; t < T; ++t) M = fmaxf(M, pms[(size_t)t * 2 * NS + n]);
-        float S = 0.f;
-#pragma unroll 8
-        for (int t = 0; t < T; ++t) S += pms[(size_t)t * 2 * NS + NS + n] * __expf(pms[(size_t)t * 2 * NS + n] - M);
-        Ms[tid] = M;
-        Ss[tid] = S;
-        st[n] = M;
-        st[NS + n] = S;
+    {   // M, S of this workgroup's GN columns over the T tile partials: 32 partitions of tiles per column in parallel (as 8
+        // threads walking 2 T dependent loads this phase alone took ~10 us of the kernel's 15)
+        __shared__ float pr[32][GN];
+        const int nl = tid & (GN - 1), tp = tid / GN, n = nb + nl;
+        float m = -INFINITY;
+        for (int t = tp; t < T; t += 32) m = fmaxf(m, pms[(size_t)t * 2 * NS + n]);
+        pr[tp][nl] = m;
+        __syncthreads();
+        if (tid < GN) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) M = fmaxf(M, pr[k][tid]);
+            Ms[tid] = M;
+        }
+        __syncthreads();
+        const float M = Ms[nl];
+        float sacc = 0.f;
+        for (int t = tp; t < T; t += 32) sacc += pms[(size_t)t * 2 * NS + NS + n] * __expf(pms[(size_t)t * 2 * NS + n] - M);
+        pr[tp][nl] = sacc;
+        __syncthreads();
+        if (tid < GN) {
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) S += pr[k][tid];          // fixed order
+            Ss[tid] = S;
+            st[nb + tid] = Ms[tid];
+            st[NS + nb + tid] = S;
+        }
     }
     __syncthreads();
     for (int e = tid; e < C * GN; e += 256) {  // e = nl*C + c (the partial layout is [n][C])

@@ -276,8 +276,10 @@ class KM_UNetV3(nn.Module):
         size = ref.shape[2:]
         # bilinear resampling with align_corners=True onto the same grid is the identity (every sample lands on a pixel)
         same = lambda t: tuple(t.shape[2:]) == tuple(size)
-        a = e1 if same(e1) else F.interpolate(e1, size=size, mode="bilinear", align_corners=True)
-        b = e2 if same(e2) else F.interpolate(e2, size=size, mode="bilinear", align_corners=True)
+        rs = (lambda t: ops.resize_bilinear(t, size)) if (ref.is_cuda and "resize" not in _TORCH_GLUE) else \
+            (lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=True))
+        a = e1 if same(e1) else rs(e1)
+        b = e2 if same(e2) else rs(e2)
         return fusion([a, b, b])                 # third level is e2 again (KM_UNetV3_SH.py:495,509)
 
     def forward(self, x):

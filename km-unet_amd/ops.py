@@ -259,6 +259,35 @@ def conv_kxk(x, weight, bias=None):
 conv3x3 = conv_kxk
 
 
+class ResizeBilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode="bilinear", align_corners=True) (KM_UNetV3_SH.py:487-492, 503-507), csrc/resize.hip."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, C, Hi, Wi = x.shape
+        y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("resize_bilinear_fwd", (B, C, Hi, Wi, Ho, Wo)), lib.kmu_resize_bilinear_ac_fwd, _ptr(x), _ptr(y), B, C, Hi, Wi,
+                         Ho, Wo, _stream()), "kmu_resize_bilinear_ac_fwd")
+        ctx.dims = (B, C, Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        B, C, Hi, Wi, Ho, Wo = ctx.dims
+        gy = _f32c(gy, "gy")
+        dx = torch.empty(B, C, Hi, Wi, device=gy.device, dtype=torch.float32)
+        _lib.check(_call(("resize_bilinear_bwd", (B, C, Hi, Wi, Ho, Wo)), lib.kmu_resize_bilinear_ac_bwd, _ptr(gy), _ptr(dx), B, C, Hi, Wi,
+                         Ho, Wo, _stream()), "kmu_resize_bilinear_ac_bwd")
+        return dx, None, None
+
+
+def resize_bilinear(x, size):
+    return ResizeBilinearFn.apply(x, int(size[0]), int(size[1]))
+
+
 # ------------------------------------------------------------------------------------------ K2
 class LayerNorm1dFn(torch.autograd.Function):
     """Per-token LayerNorm over C of [B,C,L] (vim_utils_init.py:50-59)."""

@@ -718,6 +718,24 @@ def test_dagem_block_golden_with_plain_conv_stand_in(name, train):
     _report(name, **errs)
 
 
+@pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(8, 16, 64, 64, 32, 32), (8, 32, 32, 32, 64, 64), (2, 5, 7, 9, 13, 4), (1, 3, 16, 16, 1, 1),
+                                             (1, 2, 1, 5, 6, 5), (2, 16, 128, 128, 64, 64), (1, 4, 30, 30, 60, 60)])
+def test_resize_bilinear_vs_torch_cpu(B, C, Hi, Wi, Ho, Wo):
+    """F.interpolate(..., mode="bilinear", align_corners=True) and its adjoint (csrc/resize.hip) vs torch fp64 on the CPU: the
+    two pyramid resamplings of the model (64 -> 32, 32 -> 64) and ragged / degenerate extents."""
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(Hi * 31 + Wo)
+    x = torch.randn(B, C, Hi, Wi, generator=gen, dtype=torch.float64).requires_grad_(True)
+    gy = torch.randn(B, C, Ho, Wo, generator=gen, dtype=torch.float64)
+    yo = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    yo.backward(gy)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    y = ops.resize_bilinear(xd, (Ho, Wo))
+    y.backward(gy.float().to(DEV))
+    _report("resize %s" % ((B, C, Hi, Wi, Ho, Wo),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad))
+
+
 def test_iwp_golden():
     import km_unet_amd
     from oracle.model import fill_parameters
