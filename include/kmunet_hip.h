@@ -285,6 +285,22 @@ int kmu_mix3_bwd(const float* dy, const float* f0, const float* f1, const float*
                  float* d_f1, float* d_f2, float* d_g_partial, int B, int n_per_sample, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * The squeeze-excite pools (nn.AdaptiveAvgPool2d(1): KM_UNetV3_SH.py:111 fusion_gate on cat(f0,f1,f2), :231 DirectionAttention,
+ * :320 ChannelAttention, :342 LocalContrastAttention):  pooled[b][t*C + c] = mean_hw f_t[b][c][:]  for n_tensors (1..3)
+ * tensors [B,C,HW] in one launch (pooling commutes with the channel concat).  Deterministic.
+ * With it the fusion gate + branch mix form one autograd node whose backward is
+ *   kmu_mix3_bwd_dg   : d_g_partial only (as kmu_mix3_bwd without the three stores)
+ *   kmu_gate_mlp_bwd  : d_pooled [B,3C]
+ *   kmu_mix3_bwd_apply: d_f_t[b][c][:] = s[b] g[b,t] dy[b][c][:] + d_pooled[b][t*C + c] / HW      (HW a multiple of 4)
+ * ------------------------------------------------------------------------------------ */
+int kmu_mean_rows(const float* f0, const float* f1, const float* f2, float* pooled, int B, int C, int HW, int n_tensors,
+                  kmu_stream_t stream);
+int kmu_mix3_bwd_dg(const float* dy, const float* f0, const float* f1, const float* f2, const float* g, const float* s,
+                    float* d_g_partial, int B, int n_per_sample, kmu_stream_t stream);
+int kmu_mix3_bwd_apply(const float* dy, const float* g, const float* s, const float* d_pooled, float* d_f0, float* d_f1, float* d_f2,
+                       int B, int C, int HW, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Tap stacking for DirectionViM's (3,1) / (1,3) projections (KM_UNetV3_SH.py:170-172): x [B,C,H,W] ->
  * out [B,3C,H,W], out[t*C + c](p) = x[c](p + (t-1) e_axis) (zero outside), axis 0 = H, 1 = W; a 3-tap conv along
  * that axis is then kmu_pwconv_* with Ci = 3C and weight W'[co, t*C + ci] = W[co, ci, t].  bwd: dx = sum of the three

@@ -9,6 +9,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libkmunet_hip.so")
+if os.environ.get("KMU_LIB_VARIANT"):      # development: an alternative build made by tools/build_variant.py (never a fallback)
+    LIB_PATH = os.path.join(_HERE, "lib", "variants", os.environ["KMU_LIB_VARIANT"], "libkmunet_hip.so")
 
 _c = ctypes
 _P, _I, _Z = _c.c_void_p, _c.c_int, _c.c_size_t
@@ -62,6 +64,9 @@ SIGNATURES = {
     "kmu_mix3_blocks": (_I, [_I]),
     "kmu_mix3_fwd": (_I, [_P] * 7 + [_I] * 2 + [_P]),
     "kmu_mix3_bwd": (_I, [_P] * 10 + [_I] * 2 + [_P]),
+    "kmu_mean_rows": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "kmu_mix3_bwd_dg": (_I, [_P] * 7 + [_I] * 2 + [_P]),
+    "kmu_mix3_bwd_apply": (_I, [_P] * 7 + [_I] * 3 + [_P]),
     "kmu_shift3_fwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
     "kmu_shift3_bwd": (_I, [_P] * 2 + [_I] * 5 + [_P]),
     "kmu_hybrid_loss_blocks": (_I, [_I] * 3),

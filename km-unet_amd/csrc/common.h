@@ -44,13 +44,15 @@ struct OpMax {
     static __device__ __forceinline__ float id() { return -INFINITY; }
     static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); }
 };
-// WIDTH = 64: total over the wave; WIDTH = 32: total over each 32-lane half.  Result broadcast to every lane of the group.
+// WIDTH = 64: total over the wave; WIDTH = 32: total over each 32-lane half; WIDTH = 16: over each 16-lane row.  Result broadcast to every lane of the group.
 template <class Op, int WIDTH>
 __device__ __forceinline__ float wave_reduce(float v) {
     v = Op::f(v, dpp_mov<0x111, 0xf>(Op::id(), v));  // row_shr:1
     v = Op::f(v, dpp_mov<0x112, 0xf>(Op::id(), v));  // row_shr:2
     v = Op::f(v, dpp_mov<0x114, 0xf>(Op::id(), v));  // row_shr:4
     v = Op::f(v, dpp_mov<0x118, 0xf>(Op::id(), v));  // row_shr:8
+    if (WIDTH == 16)                                  // lane 15 of each DPP row holds the row's total
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((threadIdx.x & 63) | 15) << 2, __builtin_bit_cast(int, v)));
     v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));  // row_bcast:15 -> rows 1, 3
     if (WIDTH == 64) {
         v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));  // row_bcast:31 -> rows 2, 3

@@ -120,7 +120,7 @@ __device__ __forceinline__ float grp_max(float v) {
 }
 template <int WIDTH>
 __device__ __forceinline__ float grp_sum(float v) {
-    static_assert(WIDTH == 64 || WIDTH == 32, "strip groups are a wave or a half wave");
+    static_assert(WIDTH == 64 || WIDTH == 32 || WIDTH == 16, "strip groups are a wave, a half wave or a DPP row");
     return kmu::wave_reduce<kmu::OpSum, WIDTH>(v);
 }
 

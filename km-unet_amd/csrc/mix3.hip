@@ -29,7 +29,54 @@ __global__ __launch_bounds__(256) void mix3_fwd_kernel(const float* __restrict__
     }
 }
 
-// df_i = (s g_i) dy ;  part[blockIdx.x][b*3 + i] = s * sum_block dy . f_i
+// pooled[b][t*C + c] = mean_{hw} f_t[b][c][hw] for up to three tensors in one launch (the fusion gate pools the channel
+// concat of the three branches: KM_UNetV3_SH.py:111-117 -- AdaptiveAvgPool2d(1) commutes with the concat); one workgroup per
+// (t, b, c) row, fixed-order tree => deterministic.  Also serves the single-tensor squeeze-excite pools (:231, :320, :342).
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                        const float* __restrict__ f2, float* __restrict__ pooled, int C, int HW, int NT) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y, t = blockIdx.z;
+    const float* src = (t == 0 ? f0 : (t == 1 ? f1 : f2)) + ((size_t)b * C + c) * HW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if ((HW & 3) == 0) {
+        const floatx4* s4 = reinterpret_cast<const floatx4*>(src);
+        for (int i = threadIdx.x; i < HW / 4; i += 256) {
+            const floatx4 v = s4[i];
+            a0 += v[0], a1 += v[1], a2 += v[2], a3 += v[3];
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) a0 += src[i];
+    }
+    const float w = kmu::wave_sum((a0 + a1) + (a2 + a3));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) pooled[(size_t)b * NT * C + t * C + c] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)HW;
+}
+
+// second half of the composite node's backward:  d f_t[b][c][hw] = (s g_t)[b] dy[b][c][hw] + d pooled[b][t*C + c] / HW
+__global__ __launch_bounds__(256) void mix3_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ g,
+                                                             const float* __restrict__ s, const float* __restrict__ dpool,
+                                                             float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
+                                                             int n4, int C, int HW4, float inv_hw) {
+    const int b = blockIdx.y;
+    const float sc = s ? s[b] : 1.f;
+    const float k0 = sc * g[b * 3], k1 = sc * g[b * 3 + 1], k2 = sc * g[b * 3 + 2];
+    const size_t base = (size_t)b * n4;
+    const float* dp = dpool + (size_t)b * 3 * C;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int i = (blockIdx.x * VPT + v) * 256 + threadIdx.x;
+        if (i >= n4) break;
+        const int c = i / HW4;
+        const floatx4 gy = reinterpret_cast<const floatx4*>(dy)[base + i];
+        reinterpret_cast<floatx4*>(d0)[base + i] = k0 * gy + dp[c] * inv_hw;
+        reinterpret_cast<floatx4*>(d1)[base + i] = k1 * gy + dp[C + c] * inv_hw;
+        reinterpret_cast<floatx4*>(d2)[base + i] = k2 * gy + dp[2 * C + c] * inv_hw;
+    }
+}
+
+// df_i = (s g_i) dy ;  part[blockIdx.x][b*3 + i] = s * sum_block dy . f_i        (WRITE = false: the partial sums only)
+template <bool WRITE>
 __global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ f0,
                                                        const float* __restrict__ f1, const float* __restrict__ f2,
                                                        const float* __restrict__ g, const float* __restrict__ s, float* __restrict__ d0,
@@ -47,9 +94,11 @@ __global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* __restrict__
         if (i >= n4) break;
         const floatx4 gy = reinterpret_cast<const floatx4*>(dy)[base + i], a = reinterpret_cast<const floatx4*>(f0)[base + i],
                       bb = reinterpret_cast<const floatx4*>(f1)[base + i], c = reinterpret_cast<const floatx4*>(f2)[base + i];
-        reinterpret_cast<floatx4*>(d0)[base + i] = k0 * gy;
-        reinterpret_cast<floatx4*>(d1)[base + i] = k1 * gy;
-        reinterpret_cast<floatx4*>(d2)[base + i] = k2 * gy;
+        if (WRITE) {
+            reinterpret_cast<floatx4*>(d0)[base + i] = k0 * gy;
+            reinterpret_cast<floatx4*>(d1)[base + i] = k1 * gy;
+            reinterpret_cast<floatx4*>(d2)[base + i] = k2 * gy;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             a0 += gy[q] * a[q];
@@ -85,7 +134,40 @@ extern "C" int kmu_mix3_bwd(const float* dy, const float* f0, const float* f1, c
     KMU_REQUIRE(dy && f0 && f1 && f2 && g && d_f0 && d_f1 && d_f2 && d_g_partial, "mix3_bwd: null pointer");
     KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_bwd: C*H*W = %d must be a positive multiple of 4",
                 n_per_sample);
-    hipLaunchKernelGGL(mix3_bwd_kernel, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, dy, f0, f1, f2, g, s, d_f0,
+    hipLaunchKernelGGL(mix3_bwd_kernel<true>, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, dy, f0, f1, f2, g, s, d_f0,
                        d_f1, d_f2, d_g_partial, n_per_sample / 4, B);
     return kmu::launch_status("mix3_bwd");
+}
+
+// ---- the fusion gate + branch mix as ONE autograd node (KM_UNetV3_SH.py:111-117 + :141-146) -------------------------------
+//   forward : pooled = mean_hw(cat(f0, f1, f2))  ->  [gate MLP: kmu_gate_mlp_fwd]  ->  kmu_mix3_fwd
+//   backward: kmu_mix3_bwd_dg (partials of d g)  ->  [kmu_gate_mlp_bwd: d pooled]  ->  kmu_mix3_bwd_apply
+// instead of 3 mean + cat forward and 3 (grad / HW).expand + 3 fan-in adds backward as separate full-tensor launches.
+extern "C" int kmu_mean_rows(const float* f0, const float* f1, const float* f2, float* pooled, int B, int C, int HW, int n_tensors,
+                             kmu_stream_t stream) {
+    KMU_REQUIRE(f0 && pooled && (n_tensors < 2 || f1) && (n_tensors < 3 || f2), "mean_rows: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0 && n_tensors >= 1 && n_tensors <= 3, "mean_rows: bad dims B=%d C=%d HW=%d n=%d", B, C,
+                HW, n_tensors);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(C, B, n_tensors), dim3(256), 0, (hipStream_t)stream, f0, f1, f2, pooled, C, HW, n_tensors);
+    return kmu::launch_status("mean_rows");
+}
+
+extern "C" int kmu_mix3_bwd_dg(const float* dy, const float* f0, const float* f1, const float* f2, const float* g, const float* s,
+                               float* d_g_partial, int B, int n_per_sample, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && f0 && f1 && f2 && g && d_g_partial, "mix3_bwd_dg: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_bwd_dg: C*H*W = %d must be a positive multiple of 4",
+                n_per_sample);
+    hipLaunchKernelGGL(mix3_bwd_kernel<false>, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, dy, f0, f1, f2, g, s,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, d_g_partial, n_per_sample / 4, B);
+    return kmu::launch_status("mix3_bwd_dg");
+}
+
+extern "C" int kmu_mix3_bwd_apply(const float* dy, const float* g, const float* s, const float* d_pooled, float* d_f0, float* d_f1,
+                                  float* d_f2, int B, int C, int HW, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && g && d_pooled && d_f0 && d_f1 && d_f2, "mix3_bwd_apply: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0 && HW % 4 == 0, "mix3_bwd_apply: H*W = %d must be a positive multiple of 4", HW);
+    const int n = C * HW;
+    hipLaunchKernelGGL(mix3_bwd_apply_kernel, dim3(kmu_mix3_blocks(n), B), dim3(256), 0, (hipStream_t)stream, dy, g, s, d_pooled, d_f0, d_f1,
+                       d_f2, n / 4, C, HW / 4, 1.0f / (float)HW);
+    return kmu::launch_status("mix3_bwd_apply");
 }

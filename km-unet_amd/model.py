@@ -34,12 +34,41 @@ def _side_streams(device):
     return _SIDE[key]
 
 
+class _MaskPool:
+    """All stochastic-depth factors of one model forward from ONE bernoulli_ (+ one div) launch: the model draws 10 per step
+    (2 per EnhancedViMBlock), 8 floats each -- as separate draws that was 20 launches.  Rows of the block are i.i.d., so every
+    DropPath still sees an independent Bernoulli(keep) / keep vector."""
+    ROWS = 16
+
+    def __init__(self):
+        self.block, self.key, self.i = None, None, 0
+
+    def reset(self):
+        self.block = None
+
+    def next(self, x, keep, scale_by_keep):
+        key = (x.shape[0], keep, scale_by_keep, x.device, x.dtype)
+        if self.block is None or key != self.key or self.i >= self.ROWS:
+            m = torch.empty(self.ROWS, x.shape[0], device=x.device, dtype=x.dtype).bernoulli_(keep)
+            self.block, self.key, self.i = (m / keep if scale_by_keep else m), key, 0
+        self.i += 1
+        return self.block[self.i - 1]
+
+
+def _spatial_mean(x):
+    """nn.AdaptiveAvgPool2d(1) without the trailing 1x1 dims."""
+    if x.is_cuda and "gate_mlp" not in _TORCH_GLUE:
+        return ops.spatial_mean(x)
+    return x.mean(dim=(2, 3))
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm 0.9.16 semantics: mask ~ Bernoulli(1-p) / (1-p), train only)."""
 
     def __init__(self, drop_prob=0.0, scale_by_keep=True):
         super().__init__()
         self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+        self.pool = None            # set by KM_UNetV3: draws come from its per-forward block
 
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
@@ -51,6 +80,8 @@ class DropPath(nn.Module):
         if self.drop_prob == 0.0 or not self.training:
             return None
         keep = 1.0 - self.drop_prob
+        if self.pool is not None:
+            return self.pool.next(x, keep, self.scale_by_keep)
         mask = torch.empty(x.shape[0], device=x.device, dtype=x.dtype).bernoulli_(keep)
         return mask / keep if self.scale_by_keep else mask
 
@@ -92,7 +123,7 @@ class DirectionAttention(nn.Module):
 
     def forward(self, x):
         b, c = x.shape[:2]
-        gate = gate_mlp(x.mean(dim=(2, 3)), self.fc[0], self.fc[2], "gelu")
+        gate = gate_mlp(_spatial_mean(x), self.fc[0], self.fc[2], "gelu")
         qkv = conv1x1(x, self.qkv)
         if (qkv.shape[2] * qkv.shape[3]) % 4 == 0 and "qkv_gate" not in _TORCH_GLUE:
             attn = ops.qkv_gate(qkv)                       # sigmoid(q*k)*v, one HIP kernel
@@ -186,15 +217,23 @@ class EnhancedViMBlock(nn.Module):
 
     def forward(self, x):
         feats = self._branches(x)
+        dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
+        if x.is_cuda and "mix3" not in _TORCH_GLUE and "gate_mlp" not in _TORCH_GLUE and (x.shape[2] * x.shape[3]) % 4 == 0:
+            # pool -> gate MLP -> softmax -> weighted branch sum + DropPath + residual as one autograd node
+            x = ops.gated_mix3(x, feats[0], feats[1], feats[2], self.fusion_gate[1], self.fusion_gate[3],
+                               dp.scale(x) if dp is not None else None)
+            return self._ffn(x, dp)
         # fusion_gate = pool . conv1x1 . GELU . conv1x1 . softmax: pooling commutes with the channel concat
         pooled = torch.cat([f.mean(dim=(2, 3)) for f in feats], dim=1)
         g = gate_mlp(pooled, self.fusion_gate[1], self.fusion_gate[3], "gelu", "softmax")
-        dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
         if "mix3" in _TORCH_GLUE or not x.is_cuda:
             g = g[:, :, None, None]
             x = x + self.drop_path(g[:, 0:1] * feats[0] + g[:, 1:2] * feats[1] + g[:, 2:3] * feats[2])
         else:       # weighted branch sum + DropPath + residual: one HIP kernel (csrc/mix3.hip)
             x = ops.mix3(x, feats[0], feats[1], feats[2], g, dp.scale(x) if dp is not None else None)
+        return self._ffn(x, dp)
+
+    def _ffn(self, x, dp):
         f = conv1x1(conv1x1(self.norm(x), self.ffn[0]), self.ffn[2], gelu_in=True)   # GELU folded into ffn[2]'s load
         s = dp.scale(x) if dp is not None else None
         return x + f if s is None else torch.addcmul(x, f, s.view(-1, 1, 1, 1))
@@ -209,7 +248,7 @@ class ChannelAttention(nn.Module):
 
     def forward(self, x):
         b, c = x.shape[:2]
-        return x * gate_mlp(x.mean(dim=(2, 3)), self.fc[0], self.fc[2], "silu").view(b, c, 1, 1)
+        return x * gate_mlp(_spatial_mean(x), self.fc[0], self.fc[2], "silu").view(b, c, 1, 1)
 
 
 class MultiScaleFusion(nn.Module):
@@ -237,7 +276,7 @@ class LocalContrastAttention(nn.Module):
         self.fc = nn.Sequential(nn.Linear(in_channels // reduction_ratio, 64), nn.ReLU(), nn.Linear(64, in_channels), nn.Sigmoid())
 
     def forward(self, x):
-        avg = x.mean(dim=(2, 3))
+        avg = _spatial_mean(x)
         g = gate_mlp(avg.view(avg.shape[0], -1, self.reduction_ratio).mean(-1), self.fc[0], self.fc[2], "relu")[:, :, None, None]
         return torch.lerp(x, torch.ones_like(x), g)          # x*(1-g) + g
 
@@ -271,6 +310,10 @@ class KM_UNetV3(nn.Module):
         self.dec3 = nn.Sequential(up(), nn.Conv2d(e1 * 2, e0, 3, padding=1), EnhancedViMBlock(e0), nn.Conv2d(e0, num_classes, 3, padding=1))
         self.output_norm = nn.GroupNorm(1, num_classes)
         self.activation = nn.Sigmoid()
+        self._mask_pool = _MaskPool()
+        for m in self.modules():
+            if isinstance(m, DropPath):
+                m.pool = self._mask_pool
 
     def _pyramid(self, fusion, e1, e2, ref):
         size = ref.shape[2:]
@@ -283,6 +326,7 @@ class KM_UNetV3(nn.Module):
         return fusion([a, b, b])                 # third level is e2 again (KM_UNetV3_SH.py:495,509)
 
     def forward(self, x):
+        self._mask_pool.reset()
         x = conv3x3(x.float(), self.conv_f)
         e1 = self.lca1(self.enc1(x))
         e2 = self.lca2(self.enc2(e1))

@@ -335,6 +335,28 @@ class DeformConv2d(nn.Module):
         return ops.deform_conv2d(x, offset, self.weight, self.bias)
 
 
+class _SkinnyLinearFn(torch.autograd.Function):
+    """nn.Linear(k, 1) on [N, k] with N ~ 1e5 (DAGEM_md.py:18-22, :33-37).  Forward and input gradient are ATen's; the weight
+    gradient dy^T x is a [1, N] x [N, k] product that hipBLASLt serves with a 16x16x512 macro-tile kernel on ONE workgroup
+    (113 us at N = 131072, rocprof) -- as a product and a column sum it is two streaming launches (~12 us)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        return dy @ w, (x * dy).sum(0, keepdim=True), dy.sum(0)
+
+
+def _mlp(seq, x):
+    lin = seq[0]
+    y = _SkinnyLinearFn.apply(x, lin.weight, lin.bias) if (lin.out_features == 1 and x.is_cuda) else lin(x)
+    return seq[2](seq[1](y))
+
+
 class DAGEM(nn.Module):
     """DAGEM_md.py:7-111: graph-edge bridge; the deformable conv is the HIP kernel, the small MLPs are glue."""
 
@@ -355,12 +377,12 @@ class DAGEM(nn.Module):
         b, c, h, w = x.shape
         nb = torch.stack((x.roll(1, 2), x.roll(-1, 2), x.roll(1, 3), x.roll(-1, 3)), dim=-1)
         edge = nb * x.unsqueeze(-1)                                                   # [B,C,H,W,4]
-        agg = self.edge_aggregation_func(edge.reshape(-1, 4)).view(b, c, h, w)
+        agg = _mlp(self.edge_aggregation_func, edge.reshape(-1, 4)).view(b, c, h, w)
         vert = self.vertex_update_func(torch.cat((x, agg), 1).permute(0, 2, 3, 1).reshape(-1, 2 * c))
         vert = vert.view(b, h, w, c // 2).permute(0, 3, 1, 2)
         ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1).permute(0, 2, 3, 4, 1).reshape(-1, 2 * c)
         ue = self.edge_update_func(ef).view(b, h, w, 4, c // 2).permute(0, 4, 1, 2, 3).reshape(-1, 4)
-        ue = self.update_edge_reduce_func(ue).view(b, c // 2, h, w)
+        ue = _mlp(self.update_edge_reduce_func, ue).view(b, c // 2, h, w)
         deformed = self.deform_conv(x, conv3x3(x, self.offset_conv)) + x
         fa = self.final_aggregation_layer
         return fa[2](fa[1](conv1x1(torch.cat((deformed, vert * ue), 1), fa[0])))

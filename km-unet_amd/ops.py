@@ -356,7 +356,7 @@ class HsmssdFn(torch.autograd.Function):
         ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
         ctx.set_materialize_grads(False)      # EfficientViMBlock drops h: no zero tensor for its gradient
         ctx.dims = (B, C, N, Hs)
-        ctx.A_shape = A.shape
+        ctx.zero_A = _const_zeros(A)       # dL/dA == 0 exactly: a shared constant, cached here (before any graph capture)
         return y, h
 
     @staticmethod
@@ -388,7 +388,7 @@ class HsmssdFn(torch.autograd.Function):
         # returns ~1e-7 rounding noise here)
         d_bcdt, d_dw, d_hz, d_out, d_D = colsum(p_bcdt, p_dw, p_hz, p_out, p_D.view(G, 1))
         return (dx, d_bcdt.view(3 * N, C, 1), d_dw.view(3 * N, 1, 3, 3), d_hz.view(2 * C, C, 1), d_out.view(C, C, 1),
-                torch.zeros(ctx.A_shape, device=dev), d_D.view(1))
+                ctx.zero_A, d_D.view(1))
 
 
 def hsmssd(x, w_bcdt, w_dw, w_hz, w_out, A, D):
@@ -680,6 +680,96 @@ class Mix3Fn(torch.autograd.Function):
 
 def mix3(x, f0, f1, f2, g, s=None):
     return Mix3Fn.apply(x, f0, f1, f2, g, s)
+
+
+class SpatialMeanFn(torch.autograd.Function):
+    """x.mean(dim=(2, 3)) of [B,C,H,W] -> [B,C] (nn.AdaptiveAvgPool2d(1) of the squeeze-excite gates: KM_UNetV3_SH.py:231, :320,
+    :342).  One deterministic launch; the backward returns the broadcast (grad / HW) as an EXPANDED view -- autograd's fan-in add
+    consumes it without the full-size division ATen's mean backward launches."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("mean_rows", (B, C, HW)), lib.kmu_mean_rows, _ptr(x), None, None, _ptr(out), B, C, HW, 1, _stream()), "kmu_mean_rows")
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C = ctx.shape[:2]
+        HW = 1
+        for d in ctx.shape[2:]:
+            HW *= d
+        return (g * (1.0 / HW)).view(B, C, *([1] * (len(ctx.shape) - 2))).expand(ctx.shape)
+
+
+def spatial_mean(x):
+    return SpatialMeanFn.apply(x)
+
+
+class GatedMix3Fn(torch.autograd.Function):
+    """EnhancedViMBlock's fusion gate + branch mix as ONE autograd node (KM_UNetV3_SH.py:111-117, :141-146):
+        g   = softmax(W2 gelu(W1 mean_hw(cat(f0, f1, f2)) + b1) + b2)          [B,3]
+        out = x + s[b] (g0 f0 + g1 f1 + g2 f2)
+    forward 3 launches (pool, gate MLP, mix), backward 4 (d g partials, their column sum, gate MLP backward, d f_t = s g_t dy +
+    d pooled / HW) -- the separate nodes took 3 means + cat forward and 3 full-size divisions + 3 fan-in adds backward on top."""
+
+    @staticmethod
+    def forward(ctx, x, f0, f1, f2, w1, b1, w2, b2, s):
+        lib = _lib.load()
+        x, f0, f1, f2 = _f32c(x, "x"), _f32c(f0, "f0"), _f32c(f1, "f1"), _f32c(f2, "f2")
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        n = C * HW
+        dev, st = x.device, _stream()
+        Hd = w1.shape[0]
+        w1c, w2c = _f32c(w1, "w1").view(Hd, 3 * C), _f32c(w2, "w2").view(3, Hd)
+        b1c, b2c = _f32c(b1, "b1"), _f32c(b2, "b2")
+        pooled = torch.empty(B, 3 * C, device=dev, dtype=torch.float32)
+        _lib.check(_call(("mean_rows", (B, 3 * C, HW)), lib.kmu_mean_rows, _ptr(f0), _ptr(f1), _ptr(f2), _ptr(pooled), B, C, HW, 3, st),
+                   "kmu_mean_rows")
+        z1 = torch.empty(B, Hd, device=dev, dtype=torch.float32)
+        g = torch.empty(B, 3, device=dev, dtype=torch.float32)
+        _lib.check(_call(("gate_mlp_fwd", (B, 3 * C, Hd, 3)), lib.kmu_gate_mlp_fwd, _ptr(pooled), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(b2c),
+                         _ptr(z1), _ptr(g), B, 3 * C, Hd, 3, _ACT1["gelu"], _ACT2["softmax"], st), "kmu_gate_mlp_fwd")
+        sc = None if s is None else _f32c(s, "s").view(B)
+        out = torch.empty_like(x)
+        _lib.check(_call(("mix3_fwd", (B, n)), lib.kmu_mix3_fwd, _ptr(x), _ptr(f0), _ptr(f1), _ptr(f2), _ptr(g), _ptr(sc), _ptr(out), B, n, st),
+                   "kmu_mix3_fwd")
+        ctx.save_for_backward(f0, f1, f2, g, sc, pooled, w1c, w2c, z1)
+        ctx.cfg = (B, C, HW, Hd, tuple(w1.shape), tuple(w2.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        f0, f1, f2, g, sc, pooled, w1c, w2c, z1 = ctx.saved_tensors
+        B, C, HW, Hd, s1, s2 = ctx.cfg
+        n = C * HW
+        dy = _f32c(dy, "dy")
+        dev, st = dy.device, _stream()
+        part = torch.empty(lib.kmu_mix3_blocks(n), B * 3, device=dev, dtype=torch.float32)
+        _lib.check(_call(("mix3_bwd_dg", (B, n)), lib.kmu_mix3_bwd_dg, _ptr(dy), _ptr(f0), _ptr(f1), _ptr(f2), _ptr(g), _ptr(sc), _ptr(part),
+                         B, n, st), "kmu_mix3_bwd_dg")
+        (dg,) = colsum(part)
+        dpool = torch.empty_like(pooled)
+        dw1, dw2 = torch.empty(Hd, 3 * C, device=dev), torch.empty(3, Hd, device=dev)
+        db1, db2 = torch.empty(Hd, device=dev), torch.empty(3, device=dev)
+        _lib.check(_call(("gate_mlp_bwd", (B, 3 * C, Hd, 3)), lib.kmu_gate_mlp_bwd, _ptr(pooled), _ptr(w1c), _ptr(w2c), _ptr(z1), _ptr(g),
+                         _ptr(dg), _ptr(dpool), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), B, 3 * C, Hd, 3, _ACT1["gelu"], _ACT2["softmax"],
+                         st), "kmu_gate_mlp_bwd")
+        d0, d1, d2 = torch.empty_like(f0), torch.empty_like(f1), torch.empty_like(f2)
+        _lib.check(_call(("mix3_bwd_apply", (B, n)), lib.kmu_mix3_bwd_apply, _ptr(dy), _ptr(g), _ptr(sc), _ptr(dpool), _ptr(d0), _ptr(d1),
+                         _ptr(d2), B, C, HW, st), "kmu_mix3_bwd_apply")
+        return dy, d0, d1, d2, dw1.view(s1), db1, dw2.view(s2), db2, None
+
+
+def gated_mix3(x, f0, f1, f2, lin1, lin2, s=None):
+    return GatedMix3Fn.apply(x, f0, f1, f2, lin1.weight, lin1.bias, lin2.weight, lin2.bias, s)
 
 
 # ------------------------------------------------------------------------------------------ SSIM window filter

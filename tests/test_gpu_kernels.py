@@ -639,6 +639,52 @@ def test_mix3_vs_torch_cpu(B, C, H, W, drop):
             df1=rel_err(b.grad, f1.grad), df2=rel_err(c.grad, f2.grad), dg=rel_err(gd.grad, g.grad))
 
 
+@pytest.mark.parametrize("B,C,H,W,drop", [(2, 16, 32, 32, True), (3, 32, 16, 16, False), (8, 64, 32, 32, True), (1, 16, 6, 10, True)])
+def test_gated_mix3_vs_torch_cpu(B, C, H, W, drop):
+    """EnhancedViMBlock's fusion gate + mix as one node (KM_UNetV3_SH.py:111-117, :141-146) against the same arithmetic
+    in torch fp64 on the CPU: AdaptiveAvgPool2d(1) of the concat, 1x1 conv, GELU, 1x1 conv, softmax, weighted sum + DropPath + residual."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C * H + W)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
+    x, f0, f1, f2 = mk(B, C, H, W), mk(B, C, H, W), mk(B, C, H, W), mk(B, C, H, W)
+    w1, b1, w2, b2 = mk(C // 4, 3 * C, 1, 1), mk(C // 4), mk(3, C // 4, 1, 1), mk(3)
+    s = (torch.rand(B, generator=gen, dtype=torch.float64) > 0.3).double() / 0.7 if drop else None
+    gy = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64)
+    pooled = F.adaptive_avg_pool2d(torch.cat((f0, f1, f2), 1), 1)
+    g = torch.softmax(F.conv2d(F.gelu(F.conv2d(pooled, w1, b1)), w2, b2), dim=1)
+    mix = g[:, 0:1] * f0 + g[:, 1:2] * f1 + g[:, 2:3] * f2
+    yo = x + (mix if s is None else mix * s.view(B, 1, 1, 1))
+    yo.backward(gy)
+    dev = lambda t: t.detach().float().to(DEV).requires_grad_(True)
+    xd, a, b, c = dev(x), dev(f0), dev(f1), dev(f2)
+    l1, l2 = nn.Conv2d(3 * C, C // 4, 1).to(DEV), nn.Conv2d(C // 4, 3, 1).to(DEV)
+    with torch.no_grad():
+        l1.weight.copy_(w1.float()); l1.bias.copy_(b1.float()); l2.weight.copy_(w2.float()); l2.bias.copy_(b2.float())
+    y = ops.gated_mix3(xd, a, b, c, l1, l2, None if s is None else s.float().to(DEV))
+    y.backward(gy.float().to(DEV))
+    _report("gated_mix3 %s" % ((B, C, H, W, drop),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad), df0=rel_err(a.grad, f0.grad),
+            df1=rel_err(b.grad, f1.grad), df2=rel_err(c.grad, f2.grad), dw1=rel_err(l1.weight.grad, w1.grad), db1=rel_err(l1.bias.grad, b1.grad),
+            dw2=rel_err(l2.weight.grad, w2.grad), db2=rel_err(l2.bias.grad, b2.grad))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 32, 32), (3, 64, 7, 9), (8, 32, 64, 64)])
+def test_spatial_mean_vs_torch_cpu(B, C, H, W):
+    """AdaptiveAvgPool2d(1) of the squeeze-excite gates; the backward is an expanded view that must add up with a second
+    consumer's dense gradient exactly like ATen's mean backward."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
+    wv = torch.randn(B, C, generator=gen, dtype=torch.float64)
+    gy = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64)
+    ((x.mean(dim=(2, 3)) * wv).sum() + (x * x * gy).sum()).backward()
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    m = ops.spatial_mean(xd)
+    ((m * wv.float().to(DEV)).sum() + (xd * xd * gy.float().to(DEV)).sum()).backward()
+    _report("spatial_mean %s" % ((B, C, H, W),), y=rel_err(m, x.mean(dim=(2, 3))), dx=rel_err(xd.grad, x.grad))
+
+
 @pytest.mark.parametrize("B,C,Co,H,W,axis", [(2, 16, 16, 16, 16, 0), (2, 16, 16, 16, 16, 1), (1, 32, 32, 8, 16, 0), (3, 64, 64, 8, 8, 1)])
 def test_conv3tap_vs_torch_cpu(B, C, Co, H, W, axis):
     """(3,1) / (1,3) convolutions as tap stacking (csrc/shift3.hip) + pointwise conv, against F.conv2d in fp64."""

@@ -15,16 +15,18 @@ w = [torch.randn(3 * N, C, 1, device=d) / 4, torch.randn(3 * N, 1, 3, 3, device=
      torch.randn(C, C, 1, device=d) / 4, torch.ones(N, device=d), torch.ones(1, device=d)]
 w = [t.requires_grad_(True) for t in w]
 gy = torch.randn(B, C, Hs, Hs, device=d)
-xk = torch.randn(B, 16, 128, 128, device=d)
+xk = torch.randn(B, 16, 128, 128, device=d, requires_grad=True)
 grid = km_unet_amd.KANLinear(144, 16).grid.to(d)
-kw = [torch.randn(16, 144, device=d) * 0.1, torch.randn(16, 144, 8, device=d) * 0.1, torch.randn(16, 144, device=d)]
-xc = torch.randn(B, 64, 128, 128, device=d)
-wc = torch.randn(16, 64, 3, 3, device=d) * 0.05
+kw = [t.requires_grad_(True) for t in (torch.randn(16, 144, device=d) * 0.1, torch.randn(16, 144, 8, device=d) * 0.1, torch.randn(16, 144, device=d))]
+xc = torch.randn(B, 64, 128, 128, device=d, requires_grad=True)
+wc = (torch.randn(16, 64, 3, 3, device=d) * 0.05).requires_grad_(True)
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     y, h = ops.hsmssd(x, *w)
     y.backward(gy)
-    ops.kan_conv2d(xk, grid, *kw)
-    ops.conv3x3(xc, wc, None)
+    yk = ops.kan_conv2d(xk, grid, *kw)               # K1 forward + input / weight gradients (matrix core)
+    yk.backward(gy)
+    yc = ops.conv3x3(xc, wc, None)                   # plain 3x3 conv 64 -> 16: forward, dgrad, wgrad
+    yc.backward(gy)
 torch.cuda.synchronize()
 print("done")
 
