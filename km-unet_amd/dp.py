@@ -14,6 +14,8 @@ gradients are averaged.  Design notes (MI355X):
   * BatchNorm uses per-replica batch statistics, exactly like the reference on one GPU (no SyncBN,
     DAGEM_md.py:8-12 ignores its sync_bn flag); buffers are broadcast from rank 0 at start-up.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -102,7 +104,19 @@ class DataParallel:
         node per parameter, each an `add` kernel into its (zeroed) bucket view: 664 launches of ~4 us per step on
         MI355X, 9 % of the step.  autograd.grad hands the gradients back instead and the bucket takes them with
         one multi-tensor copy; nothing needs zeroing because every live parameter is overwritten."""
-        self.bucket.store(torch.autograd.grad(loss, self.bucket.params))
+        if not loss.is_cuda or os.environ.get("KMU_WGRAD_OVERLAP", "1") != "1":
+            self.bucket.store(torch.autograd.grad(loss, self.bucket.params))
+            return
+        # parameter-gradient kernels are queued and dealt onto side streams in batches, off the activation-gradient chain
+        # (ops._wgrad); they are joined here, before the bucket copy reads their results
+        from . import ops
+        ops.WGRAD_OVERLAP = True
+        try:
+            grads = torch.autograd.grad(loss, self.bucket.params)
+        finally:
+            ops.WGRAD_OVERLAP = False
+            ops.flush_wgrad_jobs(final=True)
+        self.bucket.store(grads)
 
     def all_reduce_grads(self):
         if not self.collective:

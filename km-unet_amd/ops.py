@@ -4,6 +4,8 @@ Every function takes/returns CUDA(ROCm) fp32 tensors and launches on torch's cur
 so calls are stream-ordered with the surrounding PyTorch glue and hipGraph-capturable.  A CPU
 tensor (or a missing library) raises: the hot path has no fallback.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -65,13 +67,77 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def colsum(*partials):
+# ---- weight gradients off the critical path ---------------------------------------------------------------------------------
+# The backward pass is one dependent chain of activation-gradient kernels; every parameter-gradient kernel (1x1 / 3x3 / depthwise
+# weight gradients, their slab reductions, column sums) hangs off that chain as a leaf that nothing waits for until the optimizer
+# runs -- ~2.8 ms of ~17 ms kernel time per step at B = 8, in launches far too small to fill 256 CUs.  With WGRAD_OVERLAP set
+# (DataParallel.backward does) such a leaf is not launched where autograd reaches it: `_wgrad(job)` queues the closure (its
+# outputs are allocated at once and handed to autograd unfilled -- nothing reads a parameter gradient before the bucket copy),
+# and every WGRAD_BATCH jobs the queue is dealt round-robin onto a few side streams that first wait for the streams the jobs'
+# inputs were produced on.  flush_wgrad_jobs(final=True) drains the queue and makes the current stream wait for the side streams.
+# Forking per job instead (one event per weight gradient, ~300 per step) was measured SLOWER than the serial order inside the
+# captured graph (16.9 vs 15.05 ms/step): every cross-stream edge costs the main chain more than the ~5 us leaf it moves.
+# Off by default: a bare `.backward()` followed by a read of `.grad` must see finished gradients.
+WGRAD_OVERLAP = False
+WGRAD_BATCH = int(os.environ.get("KMU_WGRAD_BATCH", "4096"))
+WGRAD_STREAMS = int(os.environ.get("KMU_WGRAD_STREAMS", "3"))
+_WG_SIDE = {}
+_WG_JOBS = []
+_WG_BUSY = set()
+
+
+def _leaf(*ts):
+    """True when every given tensor is a leaf (a parameter handed to the op as it is).  Only then may its gradient be filled in
+    later: a weight that reaches the op through autograd operations (conv3tap's permuted taps, TripleNorm's summed affine
+    parameters) has its gradient READ by those operations' backward right after the node returns."""
+    return all(t is None or t.grad_fn is None for t in ts)
+
+
+def _wgrad(job, defer=True):
+    if not (WGRAD_OVERLAP and defer):
+        job()
+        return
+    _WG_JOBS.append((torch.cuda.current_stream(), job))
+    if len(_WG_JOBS) >= WGRAD_BATCH:
+        flush_wgrad_jobs(final=False)
+
+
+def flush_wgrad_jobs(final=True):
+    """Launch the queued weight-gradient jobs on the side streams; final: also make the current stream wait for them."""
+    cur = torch.cuda.current_stream()
+    if _WG_JOBS:
+        dev = cur.device
+        sides = _WG_SIDE.get(dev.index)
+        if sides is None or len(sides) != WGRAD_STREAMS:
+            sides = _WG_SIDE[dev.index] = [torch.cuda.Stream(device=dev) for _ in range(WGRAD_STREAMS)]
+        producers = {}
+        for st, _ in _WG_JOBS:
+            producers[st.cuda_stream] = st
+        events = [st.record_event() for st in producers.values()]
+        for side in sides:
+            for ev in events:
+                side.wait_event(ev)
+            _WG_BUSY.add(side)
+        for i, (_, job) in enumerate(_WG_JOBS):
+            with torch.cuda.stream(sides[i % len(sides)]):
+                job()
+        _WG_JOBS.clear()        # inputs die here: their blocks go back to the producers' pools, whose next kernels are ordered
+                                # behind the join below (main) or behind the next forward's fork from main (branch streams)
+    if final:
+        for side in _WG_BUSY:
+            cur.wait_stream(side)
+        _WG_BUSY.clear()
+
+
+def colsum(*partials, outs=None):
     """Column sums of per-workgroup partial arrays [rows, ...] -> [...] for up to 8 arrays in ONE launch
-    (csrc/colsum.hip): the second stage of every deterministic two-stage parameter-gradient reduction."""
+    (csrc/colsum.hip): the second stage of every deterministic two-stage parameter-gradient reduction.
+    outs: preallocated results, one per non-None partial (deferred weight-gradient jobs)."""
     import ctypes
     lib = _lib.load()
     parts = [p for p in partials if p is not None]
-    outs = [torch.empty(p.shape[1:], device=p.device, dtype=torch.float32) for p in parts]
+    if outs is None:
+        outs = [torch.empty(p.shape[1:], device=p.device, dtype=torch.float32) for p in parts]
     n = len(parts)
     srcs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts])
     dsts = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
@@ -121,6 +187,7 @@ class KanConv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, grid, base_w, spline_w, scaler, residual, relu):
+        ctx.defer_wgrad = _leaf(base_w, spline_w, scaler)
         lib = _lib.load()
         x = _f32c(x, "x")
         base_w, spline_w, scaler = _f32c(base_w, "base_weight"), _f32c(spline_w, "spline_weight"), _f32c(scaler, "spline_scaler")
@@ -183,18 +250,23 @@ class KanConv2dFn(torch.autograd.Function):
             d_bw = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
             d_sw = torch.empty(Cout, Cin * 9, 8, device=x.device, dtype=torch.float32)
             d_sc = torch.empty(Cout, Cin * 9, device=x.device, dtype=torch.float32)
-            if ctx.x3:
-                nbytes = lib.kmu_conv3x3_x3_wgrad_ws_bytes(1, B, Cin, Cout, H, W)
-                ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-                _lib.check(_call(("kan_conv2d_bwd_weights_x3", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights_x3, _ptr(x), _ptr(dy),
-                                 _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
-                                 B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights_x3")
-            else:
-                nbytes = lib.kmu_kan_bwd_ws_bytes(B, Cin, Cout, H, W)
-                ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-                _lib.check(_call(("kan_conv2d_bwd_weights", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights, _ptr(x), _ptr(dy),
-                                 _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
-                                 B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights")
+            x3 = ctx.x3
+
+            def job():
+                st = _stream()
+                if x3:
+                    nbytes = lib.kmu_conv3x3_x3_wgrad_ws_bytes(1, B, Cin, Cout, H, W)
+                    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+                    _lib.check(_call(("kan_conv2d_bwd_weights_x3", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights_x3, _ptr(x), _ptr(dy),
+                                     _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
+                                     B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights_x3")
+                else:
+                    nbytes = lib.kmu_kan_bwd_ws_bytes(B, Cin, Cout, H, W)
+                    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+                    _lib.check(_call(("kan_conv2d_bwd_weights", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights, _ptr(x), _ptr(dy),
+                                     _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
+                                     B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights")
+            _wgrad(job, ctx.defer_wgrad)
         return dx, None, d_bw, d_sw, d_sc, (dy if ctx.has_res else None), None
 
 
@@ -209,6 +281,7 @@ class ConvKxKFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        ctx.defer_wgrad = _leaf(weight, bias)
         lib = _lib.load()
         x, weight = _f32c(x, "x"), _f32c(weight, "weight")
         bias = _f32c(bias, "bias") if bias is not None else None
@@ -241,14 +314,21 @@ class ConvKxKFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.check(_call(("conv%dx%d_dgrad_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_fwd_x3, _ptr(dy), _ptr(wp), None, _ptr(dx),
                              B, Cout, Cin, H, W, K, st), "kmu_conv2d_fwd_x3 (dgrad)")
-        if ctx.needs_input_grad[1]:       # dW[o][c][tap] = sum_pix dy[o][pix] x[c][pix + tap - K//2]: transposed-read contraction
-            nbytes = lib.kmu_conv2d_x3_wgrad_ws_bytes(B, Cin, Cout, H, W, K)
-            ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            _lib.check(_call(("conv%dx%d_bwd_weight_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_bwd_weight_x3, _ptr(x), _ptr(dy),
-                             _ptr(dw), _ptr(ws), nbytes, B, Cin, Cout, H, W, K, st), "kmu_conv2d_bwd_weight_x3")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=(0, 2, 3))
+            db = torch.empty(Cout, device=x.device, dtype=torch.float32)
+
+        def job():
+            if dw is not None:     # dW[o][c][tap] = sum_pix dy[o][pix] x[c][pix + tap - K//2]: transposed-read contraction
+                nbytes = lib.kmu_conv2d_x3_wgrad_ws_bytes(B, Cin, Cout, H, W, K)
+                ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+                _lib.check(_call(("conv%dx%d_bwd_weight_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_bwd_weight_x3, _ptr(x), _ptr(dy),
+                                 _ptr(dw), _ptr(ws), nbytes, B, Cin, Cout, H, W, K, _stream()), "kmu_conv2d_bwd_weight_x3")
+            if db is not None:
+                torch.sum(dy, dim=(0, 2, 3), out=db)
+        if dw is not None or db is not None:
+            _wgrad(job, ctx.defer_wgrad)
         return dx, dw, db
 
 
@@ -526,6 +606,7 @@ class DwConv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        ctx.defer_wgrad = _leaf(weight, bias)
         lib = _lib.load()
         x, w = _f32c(x, "x"), _f32c(weight, "weight")
         b = _f32c(bias, "bias") if bias is not None else None
@@ -552,13 +633,17 @@ class DwConv3x3Fn(torch.autograd.Function):
             _lib.check(_call(("dwconv3x3_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_data, _ptr(dy), _ptr(w), _ptr(dx), B, C, H,
                              W, st), "kmu_dwconv3x3_bwd_data")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            P = lib.kmu_dwconv3x3_partials(B)
-            dwp = torch.empty(P, C, 9, device=x.device, dtype=torch.float32)
-            dbp = torch.empty(P, C, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-            _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dy), _ptr(dwp),
-                             _ptr(dbp), B, C, H, W, st), "kmu_dwconv3x3_bwd_weight")
-            dw, db = colsum(dwp, dbp)
-            dw = dw.view(C, 1, 3, 3)
+            dw = torch.empty(C, 1, 3, 3, device=x.device, dtype=torch.float32)
+            db = torch.empty(C, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+
+            def job():
+                P = lib.kmu_dwconv3x3_partials(B)
+                dwp = torch.empty(P, C, 9, device=x.device, dtype=torch.float32)
+                dbp = torch.empty(P, C, device=x.device, dtype=torch.float32) if db is not None else None
+                _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dy), _ptr(dwp),
+                                 _ptr(dbp), B, C, H, W, _stream()), "kmu_dwconv3x3_bwd_weight")
+                colsum(dwp, dbp, outs=[dw.view(C, 9)] + ([db] if db is not None else []))
+            _wgrad(job, ctx.defer_wgrad)
         return dx, dw, db
 
 
@@ -962,12 +1047,11 @@ def _k_pw_fwd(lib, x, w):
     return y
 
 
-def _k_pw_wgrad(lib, x, gy):
+def _k_pw_wgrad(lib, x, gy, dw):
     B, ci, H, W = x.shape
     co, P = gy.shape[1], H * W
     nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-    dw = torch.empty(co, ci, device=x.device, dtype=torch.float32)
     _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight, _ptr(x), _ptr(gy), _ptr(dw), None, _ptr(ws), nbytes, B,
                      ci, co, P, 0, _stream()), "kmu_pwconv_bwd_weight")
     return dw
@@ -979,6 +1063,7 @@ class DwBnBlendFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_dw, gamma, beta, a_row, rm, rv, momentum, eps, training, nbt):
+        ctx.defer_wgrad = _leaf(w_dw)
         lib = _lib.load()
         x, w, a_row = _f32c(x, "x"), _f32c(w_dw, "weight"), _f32c(a_row, "alpha row")
         B, C, H, W = x.shape
@@ -1001,11 +1086,15 @@ class DwBnBlendFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         _lib.check(_call(("dwconv3x3_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_data_add, _ptr(dt), _ptr(w), _ptr(dxb), _ptr(dx), B, C, H, W,
                          st), "kmu_dwconv3x3_bwd_data_add")
-        P = lib.kmu_dwconv3x3_partials(B)
-        dwp = torch.empty(P, C, 9, device=x.device, dtype=torch.float32)
-        _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dt), _ptr(dwp), None, B, C, H, W, st),
-                   "kmu_dwconv3x3_bwd_weight")
-        (dw,) = colsum(dwp)
+        dw = torch.empty(C, 9, device=x.device, dtype=torch.float32)
+
+        def job():
+            P = lib.kmu_dwconv3x3_partials(B)
+            dwp = torch.empty(P, C, 9, device=x.device, dtype=torch.float32)
+            _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dt), _ptr(dwp), None, B, C, H, W,
+                             _stream()), "kmu_dwconv3x3_bwd_weight")
+            colsum(dwp, outs=[dw])
+        _wgrad(job, ctx.defer_wgrad)
         return dx, dw.view(wshape), dg, db, da, None, None, None, None, None, None
 
 
@@ -1015,6 +1104,7 @@ class FfnBlendFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, rm1, rv1, mom1, eps1, nbt1, w2, g2, b2, rm2, rv2, mom2, eps2, nbt2, a_row, training):
+        ctx.defer_wgrad = _leaf(w1, w2)
         lib = _lib.load()
         x, a_row = _f32c(x, "x"), _f32c(a_row, "alpha row")
         hid, C = w1.shape[0], w1.shape[1]
@@ -1038,12 +1128,14 @@ class FfnBlendFn(torch.autograd.Function):
         dh = torch.empty_like(h)
         _lib.check(_call(("pwconv_bwd_input", (B, hid, C, P)), lib.kmu_pwconv_bwd_input, _ptr(dz2), _ptr(w2), None, _ptr(dh), B, hid, C, P, 0, st),
                    "kmu_pwconv_bwd_input")
-        dw2 = _k_pw_wgrad(lib, h, dz2)
+        dw2 = torch.empty(C, hid, device=x.device, dtype=torch.float32)
+        _wgrad(lambda: _k_pw_wgrad(lib, h, dz2, dw2), ctx.defer_wgrad)
         dz1, _, dg1, db1, _ = _k_bn_bwd(lib, dh, z1, None, g1, b1, None, st1, 1, training)
         dx = torch.empty_like(x)
         _lib.check(_call(("pwconv_bwd_input", (B, C, hid, P)), lib.kmu_pwconv_bwd_input_add, _ptr(dz1), _ptr(w1), _ptr(dxb), _ptr(dx), B, C, hid, P,
                          st), "kmu_pwconv_bwd_input_add")
-        dw1 = _k_pw_wgrad(lib, x, dz1)
+        dw1 = torch.empty(hid, C, device=x.device, dtype=torch.float32)
+        _wgrad(lambda: _k_pw_wgrad(lib, x, dz1, dw1), ctx.defer_wgrad)
         return (dx, dw1.view(s1), dg1, db1, None, None, None, None, None, dw2.view(s2), dg2, db2, None, None, None, None, None, da, None)
 
 
@@ -1108,6 +1200,7 @@ class PwConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, act_in):
+        ctx.defer_wgrad = _leaf(weight, bias)
         lib = _lib.load()
         x = _f32c(x, "x")
         co, ci = weight.shape[:2]
@@ -1134,12 +1227,15 @@ class PwConvFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.check(_call(("pwconv_bwd_input", (B, ci, co, P)), lib.kmu_pwconv_bwd_input, _ptr(g), _ptr(w),
                              _ptr(x) if act_in else None, _ptr(dx), B, ci, co, P, act_in, _stream()), "kmu_pwconv_bwd_input")
-        nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)
-        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
         dw = torch.empty(co, ci, device=x.device, dtype=torch.float32)
         db = torch.empty(co, device=x.device, dtype=torch.float32) if has_bias else None
-        _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight, _ptr(x), _ptr(g), _ptr(dw), _ptr(db),
-                         _ptr(ws), nbytes, B, ci, co, P, act_in, _stream()), "kmu_pwconv_bwd_weight")
+
+        def job():
+            nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)
+            ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+            _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight, _ptr(x), _ptr(g), _ptr(dw), _ptr(db),
+                             _ptr(ws), nbytes, B, ci, co, P, act_in, _stream()), "kmu_pwconv_bwd_weight")
+        _wgrad(job, ctx.defer_wgrad)
         return dx, dw.view(wshape), db, None
 
 

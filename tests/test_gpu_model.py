@@ -272,3 +272,32 @@ def test_branch_streams_match_serial(monkeypatch):
     # 1e-3: a missing stream dependency shows up as O(1); what remains is the atomic-order noise of DySample / deformable-conv
     # backward amplified by cancellation in scalar parameters (HSMSSD.D: 1.9e-4 observed)
     assert worst[1] < 1e-3
+
+
+def test_wgrad_side_streams_match_serial(monkeypatch):
+    """Parameter-gradient kernels queued and dealt onto side streams (ops._wgrad, switched on by DataParallel.backward) against the serial
+    order, through the same TrainStep: identical loss, parameter gradients equal up to the atomic-order noise of DySample /
+    deformable-conv backward.  A missing dependency or a buffer recycled under a running side-stream kernel shows up as O(1)."""
+    import km_unet_amd
+    from km_unet_amd import train as T
+    from oracle.model import fill_parameters
+    m = fill_parameters(km_unet_amd.KM_UNetV3(num_classes=5), 8).cuda().train()
+    for sub in m.modules():
+        if hasattr(sub, "drop_prob"):
+            sub.drop_prob = 0.0
+    data = torch.rand(2, 10, 1, 64, 64, generator=torch.Generator().manual_seed(43)).cuda()
+    step = T.TrainStep(m, data, lr=0.0, weight_decay=0.0, loss="mse")
+    res = {}
+    for flag in ("0", "1", "1"):
+        monkeypatch.setenv("KMU_WGRAD_OVERLAP", flag)
+        step.dp.bucket.flat.fill_(float("nan"))
+        loss = step.forward_backward(data)
+        torch.cuda.synchronize()
+        res.setdefault(flag, []).append((loss.item(), step.dp.bucket.flat.clone()))
+    (l0, g0), (l1, g1), (l2, g2) = res["0"][0], res["1"][0], res["1"][1]
+    assert l0 == l1 == l2
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()
+    scale = g0.abs().max().item()
+    e1, e2 = (g1 - g0).abs().max().item() / scale, (g2 - g0).abs().max().item() / scale
+    print("  [wgrad side streams] flat-gradient difference vs serial %.2e / %.2e of the largest gradient" % (e1, e2))
+    assert e1 < 1e-5 and e2 < 1e-5

@@ -1,0 +1,9 @@
+#!/bin/bash
+O=gpurun_out/s13; mkdir -p $O
+run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run 600 python -m pytest tests/test_gpu_model.py -m gpu -q -s -x > $O/pytest_gpu.log 2>&1
+grep -E "passed|failed|^FAILED|^ERROR|wgrad side|branch streams" $O/pytest_gpu.log | tail -12 | cut -c1-250
+run 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+grep -o '"ms_per_step": [0-9.]*' $O/bench.json
+KMU_WGRAD_OVERLAP=0 run 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_serial.json 2> $O/bench_serial.err
+grep -o '"ms_per_step": [0-9.]*' $O/bench_serial.json

@@ -1,0 +1,10 @@
+#!/bin/bash
+O=gpurun_out/s14; mkdir -p $O
+run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run 600 python -m pytest tests/test_gpu_model.py -m gpu -q -s -x > $O/pytest_gpu.log 2>&1
+grep -E "passed|failed|^FAILED|^ERROR|wgrad side|branch streams" $O/pytest_gpu.log | tail -12 | cut -c1-250
+for cfg in "64 3" "1000 3" "32 3" "64 2" "128 4"; do
+  set -- $cfg
+  KMU_WGRAD_BATCH=$1 KMU_WGRAD_STREAMS=$2 run 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_$1_$2.json 2> $O/bench_$1_$2.err
+  echo "batch $1 streams $2: $(grep -o '"ms_per_step": [0-9.]*' $O/bench_$1_$2.json)"
+done
