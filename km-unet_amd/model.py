@@ -27,6 +27,16 @@ _BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") == "1"
 _SIDE = {}
 
 
+_PYR = {}
+
+
+def _pyramid_streams(device):
+    key = (device.type, device.index)
+    if key not in _PYR:
+        _PYR[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _PYR[key]
+
+
 def _side_streams(device):
     key = (device.type, device.index)
     if key not in _SIDE:
@@ -315,25 +325,48 @@ class KM_UNetV3(nn.Module):
             if isinstance(m, DropPath):
                 m.pool = self._mask_pool
 
-    def _pyramid(self, fusion, e1, e2, ref):
-        size = ref.shape[2:]
+    def _pyramid(self, fusion, e1, e2, size):
+        size = tuple(size)
         # bilinear resampling with align_corners=True onto the same grid is the identity (every sample lands on a pixel)
-        same = lambda t: tuple(t.shape[2:]) == tuple(size)
-        rs = (lambda t: ops.resize_bilinear(t, size)) if (ref.is_cuda and "resize" not in _TORCH_GLUE) else \
+        same = lambda t: tuple(t.shape[2:]) == size
+        rs = (lambda t: ops.resize_bilinear(t, size)) if (e1.is_cuda and "resize" not in _TORCH_GLUE) else \
             (lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=True))
         a = e1 if same(e1) else rs(e1)
         b = e2 if same(e2) else rs(e2)
         return fusion([a, b, b])                 # third level is e2 again (KM_UNetV3_SH.py:495,509)
+
+    def _joined(self, forked, fusion, e1, e2, ref):
+        if forked is None or tuple(forked[1].shape[2:]) != tuple(ref.shape[2:]):
+            return self._pyramid(fusion, e1, e2, ref.shape[2:])
+        st, p = forked
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(st)
+        p.record_stream(cur)
+        return p
 
     def forward(self, x):
         self._mask_pool.reset()
         x = conv3x3(x.float(), self.conv_f)
         e1 = self.lca1(self.enc1(x))
         e2 = self.lca2(self.enc2(e1))
+        # The two MultiScaleFusion pyramids read only e1 and e2 (and the SIZE of the decoder feature they are concatenated to:
+        # 1x and 2x e2's, the wavelet pooling halves and each decoder stage doubles): ~50 launches forward and ~100 backward that
+        # need not sit between the encoder and the decoder on the critical path.  Fork them onto two streams of their own here;
+        # autograd replays their backward on the same streams, beside the decoder's.
+        h2, w2 = e2.shape[2:]
+        pyr = [None, None]
+        if x.is_cuda and _BRANCH_STREAMS and h2 % 2 == 0 and w2 % 2 == 0:
+            cur = torch.cuda.current_stream()
+            ready = cur.record_event()
+            for i, (st, att, size) in enumerate(zip(_pyramid_streams(x.device), (self.attention1, self.attention2),
+                                                    ((h2, w2), (2 * h2, 2 * w2)))):
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    pyr[i] = (st, self._pyramid(att, e1, e2, size))
         e3 = self.lca3(self.enc3(e2))
         d1 = self.dec1(self.bridge_attention(e3) if self.variant == "SH" else e3)
-        d1 = torch.cat([d1, self._pyramid(self.attention1, e1, e2, d1)], dim=1)
+        d1 = torch.cat([d1, self._joined(pyr[0], self.attention1, e1, e2, d1)], dim=1)
         d2 = self.dec2[2](conv3x3(self.dec2[0](d1), self.dec2[1]))
-        d2 = torch.cat([d2, self._pyramid(self.attention2, e1, e2, d2)], dim=1)
+        d2 = torch.cat([d2, self._joined(pyr[1], self.attention2, e1, e2, d2)], dim=1)
         d3 = conv3x3(self.dec3[2](conv3x3(self.dec3[0](d2), self.dec3[1])), self.dec3[3])
         return self.activation(group_norm(d3, self.output_norm))

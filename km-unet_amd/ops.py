@@ -384,6 +384,7 @@ class LayerNorm1dFn(torch.autograd.Function):
                    "kmu_layernorm1d_fwd")
         ctx.save_for_backward(x, w, stats)
         ctx.wshape = weight.shape
+        ctx.defer_wgrad = _leaf(weight, bias)
         return y
 
     @staticmethod
@@ -398,7 +399,8 @@ class LayerNorm1dFn(torch.autograd.Function):
         dbp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
         _lib.check(lib.kmu_layernorm1d_bwd(_ptr(x), _ptr(w), _ptr(stats), _ptr(dy), _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, L,
                                            _stream()), "kmu_layernorm1d_bwd")
-        dw, db = colsum(dwp, dbp)
+        dw, db = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
+        _wgrad(lambda: colsum(dwp, dbp, outs=[dw, db]), ctx.defer_wgrad)
         return dx, dw.view(ctx.wshape), db.view(ctx.wshape), None
 
 
@@ -436,6 +438,7 @@ class HsmssdFn(torch.autograd.Function):
         ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
         ctx.set_materialize_grads(False)      # EfficientViMBlock drops h: no zero tensor for its gradient
         ctx.dims = (B, C, N, Hs)
+        ctx.defer_wgrad = _leaf(w_bcdt, w_dw, w_hz, w_out, D)
         ctx.zero_A = _const_zeros(A)       # dL/dA == 0 exactly: a shared constant, cached here (before any graph capture)
         return y, h
 
@@ -466,7 +469,9 @@ class HsmssdFn(torch.autograd.Function):
                              _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, st), "kmu_hsmssd_bwd_stage")
         # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd
         # returns ~1e-7 rounding noise here)
-        d_bcdt, d_dw, d_hz, d_out, d_D = colsum(p_bcdt, p_dw, p_hz, p_out, p_D.view(G, 1))
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        d_bcdt, d_dw, d_hz, d_out, d_D = mk(3 * N, C), mk(3 * N, 9), mk(2 * C, C), mk(C, C), mk(1)
+        _wgrad(lambda: colsum(p_bcdt, p_dw, p_hz, p_out, p_D.view(G, 1), outs=[d_bcdt, d_dw, d_hz, d_out, d_D]), ctx.defer_wgrad)
         return (dx, d_bcdt.view(3 * N, C, 1), d_dw.view(3 * N, 1, 3, 3), d_hz.view(2 * C, C, 1), d_out.view(C, C, 1),
                 ctx.zero_A, d_D.view(1))
 
@@ -1344,6 +1349,7 @@ class GroupNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, G, eps):
         lib = _lib.load()
+        ctx.defer_wgrad = _leaf(gamma, beta)
         x, gamma, beta = _f32c(x, "x"), _f32c(gamma, "weight"), _f32c(beta, "bias")
         B, C = x.shape[:2]
         HW = x.numel() // (B * C)
@@ -1369,7 +1375,8 @@ class GroupNormFn(torch.autograd.Function):
         ws = torch.empty(B * C * S * 2, device=x.device, dtype=torch.float32)
         _lib.check(_call(("group_norm_bwd", (B, C, G, HW)), lib.kmu_group_norm_bwd, _ptr(x), _ptr(g), _ptr(gamma), _ptr(stats),
                          _ptr(dx), _ptr(dgp), _ptr(dbp), _ptr(ws), B, C, G, HW, _stream()), "kmu_group_norm_bwd")
-        dg, db = colsum(dgp, dbp)
+        dg, db = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
+        _wgrad(lambda: colsum(dgp, dbp, outs=[dg, db]), ctx.defer_wgrad)
         return dx, dg, db, None, None
 
 
