@@ -44,15 +44,18 @@ RIDGE = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # FLOP/B at which f
 
 
 def pmc_traffic(name, shape):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01k_pmc_traffic.json), measured at
-    the bench shape only; None for kernels / shapes without a PMC pass."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02b_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), measured at the bench shape only; None for
+    kernels / shapes without a PMC pass."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")))["kernels"]
+        table = json.load(open(os.path.join(ROOT, "profiles", "r02b_pmc_traffic.json")))["kernels"]
     except Exception:
         return None
-    key = {("hsmssd_bwd_passB", (8, 16, 128)): "hsm_bwd_passB<16>", ("hsmssd_bwd_passA", (8, 16, 128)): "hsm_bwd_passA<16>",
-           ("hsmssd_fwd_pass1", (8, 16, 128)): "hsm_fwd_pass1<16>", ("hsmssd_fwd_pass2", (8, 16, 128)): "hsm_fwd_pass2<16>",
-           ("kan_conv2d_fwd", (8, 16, 16, 128, 128)): "kan_fwd_kernel<8, 32, 4, 1, 4, 1>"}.get((name, tuple(shape)))
+    key = {("hsmssd_bwd_passB", (8, 16, 128)): "hsm_bwd_passB<16>", ("hsmssd_bwd_passA_x3", (8, 16, 128)): "hsm_bwd_passA_x3<16>",
+           ("hsmssd_fwd_pass2_x3", (8, 16, 128)): "hsm_fwd_pass2_x3<16>",
+           ("kan_conv2d_fwd_x3", (8, 16, 16, 128, 128)): "conv3x3_x3_fwd_kernel<0, 3, 8, 32, 4, 1, 1>",
+           ("kan_conv2d_bwd_input_x3", (8, 16, 16, 128, 128)): "kan_dgrad_x3_kernel<4, 32>",
+           ("pwconv_fwd", (8, 16, 64, 16384)): "pw_gemm_kernel<4>"}.get((name, tuple(shape)))
     return table[key]["hbm_bytes"] if key in table else None
 
 
