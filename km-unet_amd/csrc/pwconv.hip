@@ -316,7 +316,13 @@ int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk,
                 what, K, N);
     KMU_REQUIRE(P > 0 && P % 64 == 0, "%s: H*W = %d must be a positive multiple of 64", what, P);
     KMU_REQUIRE(K <= 256, "%s: %d contraction channels exceed the LDS weight tile (256)", what, K);
-    switch (pick_tiles(N / 16)) {
+    // With few pixel blocks (the 32x32 level: B*P/256 = 32) a 4-tile-wide workgroup leaves most of the 256 CUs idle and walks all K
+    // channels on its own: 27.6 us for 256 -> 64 at [8, ., 32, 32] (0.38 TB/s).  Narrower channel tiles there give grid.y more
+    // workgroups; x is re-read from L2 once per channel tile, which at these sizes (<= 8 MB) is cheaper than an idle device.
+    int nt = pick_tiles(N / 16);
+    const long blocks_x = (long)B * ((P + 255) / 256);
+    while (nt > 1 && blocks_x * (N / (16 * nt)) < 192) nt = (nt == 4) ? 2 : 1;
+    switch (nt) {
         case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
         case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
         case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
