@@ -447,6 +447,54 @@ int kmu_resize_bilinear_ac_bwd(const float* gy, float* dx, int B, int C, int Hi,
 int kmu_contingency_counts(const float* pred, const float* target, unsigned long long* counts, size_t n,
                            const int* thresholds, int n_thresholds, float scale, kmu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Grouped variants.  EnhancedViMBlock (KM_UNetV3_SH.py:97-151) runs three DirectionViM branches (height / width / channel,
+ * :154-212) that differ only in their first projection: afterwards each applies the SAME layer sequence (EfficientViMBlock,
+ * efficient_vim_init.py:64-97, then DirectionAttention, :215-263) to a tensor of the same shape with its own weights.
+ * Stacked along the channel axis -- x [B, G*C, H, W], parameters [G, ...] -- every layer is one launch instead of G.
+ * Per-channel layers (depthwise conv, BatchNorm blend, qkv gate, pooling) run unchanged on G*C channels; the entry points
+ * below are the layers that mix channels.  In all of them sample index b of a [B*G, C, ...] view uses parameter set b % G.
+ *   kmu_pwconv_*_g            block-diagonal 1x1 conv: x [B, G*Ci, P] -> y [B, G*Co, P], w [G*Co, Ci], bias [G*Co];
+ *                             bwd_input_g: optional GELU' (x_pre) and addend epilogues; bwd_weight_g: ONE group per call
+ *   kmu_layernorm1d_*_g       LayerNorm1D over C of [B (= samples*G), C, L], weight / bias [G, C]; the partial rows of
+ *                             sample b belong to group b % G
+ *   kmu_hsmssd_*_stage_x3_g   HSMSSD (bf16x3 kernels) with w_bcdt [G,3N,C], w_dw [G,3N,9], w_hz [G,2C,C], w_out [G,C,C], D [G];
+ *                             workspace sizes from the *_ws_bytes*_g functions (G weight packs)
+ *   kmu_gate_mlp_*_g          G independent gate MLPs on p [B, G, I] with stacked weights; one workgroup per group
+ *   kmu_mix3_*_stacked        the branch mix on the channel slices of ONE tensor F [B, 3C, H, W] (and its gradient dF)
+ * ------------------------------------------------------------------------------------ */
+int kmu_pwconv_fwd_g(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int P, int act_in, int groups,
+                     kmu_stream_t stream);
+int kmu_pwconv_bwd_input_g(const float* gy, const float* w, const float* x_pre, const float* addend, float* dx, int B, int Ci, int Co,
+                           int P, int act_in, int groups, kmu_stream_t stream);
+int kmu_pwconv_bwd_weight_g(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci, int Co,
+                            int P, int act_in, int groups, int g, kmu_stream_t stream);
+int kmu_layernorm1d_fwd_g(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean, int B, int C, int L,
+                          float eps, int groups, kmu_stream_t stream);
+int kmu_layernorm1d_bwd_g(const float* x, const float* weight, const float* rstd_mean, const float* dy, float* dx,
+                          float* d_weight_partial, float* d_bias_partial, int B, int C, int L, int groups, kmu_stream_t stream);
+size_t kmu_hsmssd_fwd_ws_bytes_g(int B, int C, int N, int Hs, int groups);
+int kmu_hsmssd_fwd_stage_x3_g(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
+                              const float* D, float* y, float* h, float* state, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,
+                              int stage, int groups, kmu_stream_t stream);
+size_t kmu_hsmssd_bwd_ws_bytes_x3_g(int B, int C, int N, int Hs, int groups);
+int kmu_hsmssd_bwd_stage_x3_g(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
+                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
+                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
+                              float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups,
+                              kmu_stream_t stream);
+int kmu_gate_mlp_fwd_g(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, float* z1, float* g, int B,
+                       int I, int H, int O, int act1, int act2, int groups, kmu_stream_t stream);
+int kmu_gate_mlp_bwd_g(const float* p, const float* w1, const float* w2, const float* z1, const float* g, const float* dg, float* dp,
+                       float* dw1, float* db1, float* dw2, float* db2, int B, int I, int H, int O, int act1, int act2, int groups,
+                       kmu_stream_t stream);
+int kmu_mix3_fwd_stacked(const float* x, const float* F, const float* g, const float* s, float* out, int B, int n_per_sample,
+                         kmu_stream_t stream);
+int kmu_mix3_bwd_dg_stacked(const float* dy, const float* F, const float* g, const float* s, float* d_g_partial, int B,
+                            int n_per_sample, kmu_stream_t stream);
+int kmu_mix3_bwd_apply_stacked(const float* dy, const float* g, const float* s, const float* d_pooled, float* dF, int B, int C, int HW,
+                               kmu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

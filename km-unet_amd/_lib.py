@@ -108,6 +108,21 @@ SIGNATURES = {
     "kmu_conv2d_bwd_weight_x3": (_I, [_P] * 4 + [_Z] + [_I] * 6 + [_P]),
     "kmu_resize_bilinear_ac_fwd": (_I, [_P] * 2 + [_I] * 6 + [_P]),
     "kmu_resize_bilinear_ac_bwd": (_I, [_P] * 2 + [_I] * 6 + [_P]),
+    # grouped variants: the three direction branches of EnhancedViMBlock stacked along the channel axis, one launch per layer
+    "kmu_pwconv_fwd_g": (_I, [_P] * 4 + [_I] * 6 + [_P]),
+    "kmu_pwconv_bwd_input_g": (_I, [_P] * 5 + [_I] * 6 + [_P]),
+    "kmu_pwconv_bwd_weight_g": (_I, [_P] * 5 + [_Z] + [_I] * 7 + [_P]),
+    "kmu_layernorm1d_fwd_g": (_I, [_P] * 5 + [_I] * 3 + [_c.c_float, _I, _P]),
+    "kmu_layernorm1d_bwd_g": (_I, [_P] * 7 + [_I] * 4 + [_P]),
+    "kmu_hsmssd_fwd_ws_bytes_g": (_Z, [_I] * 5),
+    "kmu_hsmssd_fwd_stage_x3_g": (_I, [_P] * 10 + [_Z] + [_I] * 6 + [_P]),
+    "kmu_hsmssd_bwd_ws_bytes_x3_g": (_Z, [_I] * 5),
+    "kmu_hsmssd_bwd_stage_x3_g": (_I, [_P] * 16 + [_Z] + [_I] * 6 + [_P]),
+    "kmu_gate_mlp_fwd_g": (_I, [_P] * 7 + [_I] * 7 + [_P]),
+    "kmu_gate_mlp_bwd_g": (_I, [_P] * 11 + [_I] * 7 + [_P]),
+    "kmu_mix3_fwd_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),
+    "kmu_mix3_bwd_dg_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),
+    "kmu_mix3_bwd_apply_stacked": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 

@@ -34,19 +34,25 @@ __global__ __launch_bounds__(256) void gate_mlp_fwd_kernel(const float* __restri
                                                            const float* __restrict__ b2, float* __restrict__ z1_out,
                                                            float* __restrict__ g_out, int B, int I, int H, int O, int act1,
                                                            int act2) {
+    // gridDim.x = G gate groups with their own weights (stacked [G, ...]); row b of group g is row b*G + g of p / z1 / g
+    const int G = gridDim.x, gi = blockIdx.x;
+    w1 += (size_t)gi * H * I;
+    w2 += (size_t)gi * O * H;
+    if (b1) b1 += gi * H;
+    if (b2) b2 += gi * O;
     extern __shared__ float sm[];
     float* ps = sm;
     float* a1 = ps + B * I;
     float* z2 = a1 + B * H;
     const int tid = threadIdx.x;
-    for (int e = tid; e < B * I; e += 256) ps[e] = p[e];
+    for (int e = tid; e < B * I; e += 256) ps[e] = p[((size_t)(e / I) * G + gi) * I + e % I];
     __syncthreads();
     for (int e = tid; e < B * H; e += 256) {
         const int b = e / H, h = e - b * H;
         float s = b1 ? b1[h] : 0.f;
         const float* wr = w1 + (size_t)h * I;
         for (int i = 0; i < I; ++i) s += wr[i] * ps[b * I + i];
-        z1_out[e] = s;
+        z1_out[((size_t)b * G + gi) * H + h] = s;
         a1[e] = act1_f(s, act1);
     }
     __syncthreads();
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void gate_mlp_fwd_kernel(const float* __restri
             for (int o = 0; o < O; ++o) s += __expf(z2[b * O + o] - m);
             g = __expf(z2[e] - m) / s;
         }
-        g_out[e] = g;
+        g_out[((size_t)b * G + gi) * O + (e - b * O)] = g;
     }
 }
 
@@ -80,23 +86,35 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restri
                                                            float* __restrict__ dp, float* __restrict__ dw1, float* __restrict__ db1,
                                                            float* __restrict__ dw2, float* __restrict__ db2, int B, int I, int H,
                                                            int O, int act1, int act2) {
+    const int G = gridDim.x, gi = blockIdx.x;           // gate groups as in the forward kernel; parameter gradients per group
+    w1 += (size_t)gi * H * I;
+    w2 += (size_t)gi * O * H;
+    dw1 += (size_t)gi * H * I;
+    dw2 += (size_t)gi * O * H;
+    if (db1) db1 += gi * H;
+    if (db2) db2 += gi * O;
     extern __shared__ float sm[];
     float* ps = sm;
     float* a1 = ps + B * I;
     float* dz1 = a1 + B * H;
     float* dz2 = dz1 + B * H;
+    float* z1s = dz2 + B * O;                           // [B][H] this group's rows of z1
     const int tid = threadIdx.x;
-    for (int e = tid; e < B * I; e += 256) ps[e] = p[e];
-    for (int e = tid; e < B * H; e += 256) a1[e] = act1_f(z1[e], act1);
+    for (int e = tid; e < B * I; e += 256) ps[e] = p[((size_t)(e / I) * G + gi) * I + e % I];
+    for (int e = tid; e < B * H; e += 256) {
+        z1s[e] = z1[((size_t)(e / H) * G + gi) * H + e % H];
+        a1[e] = act1_f(z1s[e], act1);
+    }
     for (int e = tid; e < B * O; e += 256) {
         const int b = e / O;
-        const float gv = g[e];
+        const size_t r = ((size_t)b * G + gi) * O;
+        const float gv = g[r + (e - b * O)], dgv = dg[r + (e - b * O)];
         if (act2 == OUT_SIGMOID) {
-            dz2[e] = dg[e] * gv * (1.f - gv);
+            dz2[e] = dgv * gv * (1.f - gv);
         } else {
             float dot = 0.f;
-            for (int o = 0; o < O; ++o) dot += g[b * O + o] * dg[b * O + o];
-            dz2[e] = gv * (dg[e] - dot);
+            for (int o = 0; o < O; ++o) dot += g[r + o] * dg[r + o];
+            dz2[e] = gv * (dgv - dot);
         }
     }
     __syncthreads();
@@ -104,7 +122,7 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restri
         const int b = e / H, h = e - b * H;
         float s = 0.f;
         for (int o = 0; o < O; ++o) s += w2[(size_t)o * H + h] * dz2[b * O + o];
-        dz1[e] = s * act1_grad(z1[e], act1);
+        dz1[e] = s * act1_grad(z1s[e], act1);
     }
     for (int e = tid; e < O * H; e += 256) {            // dW2[o][h] = sum_b dz2[b][o] a1[b][h]
         const int o = e / H, h = e - o * H;
@@ -136,39 +154,50 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restri
             const int b = e / I, i = e - b * I;
             float s = 0.f;
             for (int h = 0; h < H; ++h) s += w1[(size_t)h * I + i] * dz1[b * H + h];
-            dp[e] = s;
+            dp[((size_t)b * G + gi) * I + i] = s;
         }
 }
 
 int check_dims(const char* what, int B, int I, int H, int O, int act1, int act2, size_t* lds) {
     KMU_REQUIRE(B > 0 && I > 0 && H > 0 && O > 0, "%s: empty problem", what);
     KMU_REQUIRE(act1 >= 0 && act1 <= 2 && act2 >= 0 && act2 <= 1, "%s: unknown activation code (%d, %d)", what, act1, act2);
-    *lds = (size_t)B * (I + 2 * H + O) * sizeof(float);
+    *lds = (size_t)B * (I + 3 * H + O) * sizeof(float);
     KMU_REQUIRE(*lds <= 144 * 1024, "%s: B=%d rows of %d+2*%d+%d floats do not fit one workgroup's LDS", what, B, I, H, O);
     return 0;
 }
 
 }  // namespace
 
-extern "C" int kmu_gate_mlp_fwd(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, float* z1,
-                                float* g, int B, int I, int H, int O, int act1, int act2, kmu_stream_t stream) {
-    KMU_REQUIRE(p && w1 && w2 && z1 && g, "gate_mlp_fwd: null pointer");
+// groups > 1: `groups` independent gates with stacked weights ([groups, H, I] ...) on p [B, groups, I] -> g [B, groups, O]
+// (DirectionAttention.fc of the three direction branches, KM_UNetV3_SH.py:231-236): one workgroup per group
+extern "C" int kmu_gate_mlp_fwd_g(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, float* z1,
+                                  float* g, int B, int I, int H, int O, int act1, int act2, int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(p && w1 && w2 && z1 && g && groups >= 1, "gate_mlp_fwd: null pointer / groups < 1");
     size_t lds;
     if (int rc = check_dims("gate_mlp_fwd", B, I, H, O, act1, act2, &lds)) return rc;
     KMU_MAX_LDS(gate_mlp_fwd_kernel, lds);
-    hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, p, w1, b1, w2, b2, z1, g, B, I, H, O, act1,
+    hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, p, w1, b1, w2, b2, z1, g, B, I, H, O, act1,
                        act2);
     return kmu::launch_status("gate_mlp_fwd");
 }
+extern "C" int kmu_gate_mlp_fwd(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, float* z1,
+                                float* g, int B, int I, int H, int O, int act1, int act2, kmu_stream_t stream) {
+    return kmu_gate_mlp_fwd_g(p, w1, b1, w2, b2, z1, g, B, I, H, O, act1, act2, 1, stream);
+}
 
-extern "C" int kmu_gate_mlp_bwd(const float* p, const float* w1, const float* w2, const float* z1, const float* g, const float* dg,
-                                float* dp, float* dw1, float* db1, float* dw2, float* db2, int B, int I, int H, int O, int act1,
-                                int act2, kmu_stream_t stream) {
-    KMU_REQUIRE(p && w1 && w2 && z1 && g && dg && dw1 && dw2, "gate_mlp_bwd: null pointer");
+extern "C" int kmu_gate_mlp_bwd_g(const float* p, const float* w1, const float* w2, const float* z1, const float* g, const float* dg,
+                                  float* dp, float* dw1, float* db1, float* dw2, float* db2, int B, int I, int H, int O, int act1,
+                                  int act2, int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(p && w1 && w2 && z1 && g && dg && dw1 && dw2 && groups >= 1, "gate_mlp_bwd: null pointer / groups < 1");
     size_t lds;
     if (int rc = check_dims("gate_mlp_bwd", B, I, H, O, act1, act2, &lds)) return rc;
     KMU_MAX_LDS(gate_mlp_bwd_kernel, lds);
-    hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, p, w1, w2, z1, g, dg, dp, dw1, db1, dw2, db2,
+    hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, p, w1, w2, z1, g, dg, dp, dw1, db1, dw2, db2,
                        B, I, H, O, act1, act2);
     return kmu::launch_status("gate_mlp_bwd");
+}
+extern "C" int kmu_gate_mlp_bwd(const float* p, const float* w1, const float* w2, const float* z1, const float* g, const float* dg,
+                                float* dp, float* dw1, float* db1, float* dw2, float* db2, int B, int I, int H, int O, int act1,
+                                int act2, kmu_stream_t stream) {
+    return kmu_gate_mlp_bwd_g(p, w1, w2, z1, g, dg, dp, dw1, db1, dw2, db2, B, I, H, O, act1, act2, 1, stream);
 }

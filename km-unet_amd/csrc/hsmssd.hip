@@ -251,8 +251,11 @@ __global__ __launch_bounds__(256) void hsm_fwd_gate(const float* __restrict__ pa
                                                     const float* __restrict__ part_acc,
                                                     const float* __restrict__ w_hz, const float* __restrict__ w_out,
                                                     const float* __restrict__ Dp, float* __restrict__ state,
-                                                    float* __restrict__ h_out, int C, int T) {
+                                                    float* __restrict__ h_out, int C, int T, int NG) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    w_hz += (size_t)(blockIdx.x % NG) * 2 * C * C;      // sample b = blockIdx.x uses weight group b % NG
+    w_out += (size_t)(blockIdx.x % NG) * C * C;
+    Dp += blockIdx.x % NG;
     float* Ms = smem;             // [GN]
     float* Ss = Ms + GN;          // [GN]
     float* hp = Ss + GN;          // [C][GN]
@@ -415,9 +418,11 @@ __global__ __launch_bounds__(256) void hsm_fwd_pass2(const float* __restrict__ x
 // =================================================================================================
 __global__ __launch_bounds__(256) void ln1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       float* __restrict__ stats, int C, int L, float eps) {
+                                                       float* __restrict__ stats, int C, int L, float eps, int G) {
     const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
     if (l >= L) return;
+    w += (b % G) * C;          // G > 1: [B, G*C, L] seen as B*G samples, sample b uses the affine parameters of group b % G
+    bias += (b % G) * C;
     const float* xp = x + (size_t)b * C * L + l;
     float mu = 0.f;
     for (int c = 0; c < C; ++c) mu += xp[(size_t)c * L];
@@ -439,9 +444,10 @@ __global__ __launch_bounds__(256) void ln1d_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void ln1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ stats, const float* __restrict__ dy,
                                                        float* __restrict__ dx, float* __restrict__ dw_part,
-                                                       float* __restrict__ db_part, int C, int L) {
+                                                       float* __restrict__ db_part, int C, int L, int G) {
     __shared__ float red[2][4];
     const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    w += (b % G) * C;
     const bool ok = l < L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t base = (size_t)b * C * L + (ok ? l : 0);
@@ -515,9 +521,11 @@ __device__ __forceinline__ void stv(float* p, const float (&src)[V]) {
 template <int C, int V>
 __global__ __launch_bounds__(256) void ln1d_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
-                                                           float* __restrict__ stats, int L, float eps) {
+                                                           float* __restrict__ stats, int L, float eps, int G) {
     const int b = blockIdx.y, l0 = (blockIdx.x * 256 + threadIdx.x) * V;
     if (l0 >= L) return;
+    w += (b % G) * C;
+    bias += (b % G) * C;
     const size_t base = (size_t)b * C * L + l0;
     float v[C][V], mu[V], rstd[V];
 #pragma unroll
@@ -558,9 +566,10 @@ template <int C, int V>
 __global__ __launch_bounds__(256) void ln1d_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ stats, const float* __restrict__ dy,
                                                            float* __restrict__ dx, float* __restrict__ dw_part,
-                                                           float* __restrict__ db_part, int L) {
+                                                           float* __restrict__ db_part, int L, int G) {
     __shared__ float red[2 * C][4];
     const int b = blockIdx.y, l0 = (blockIdx.x * 256 + threadIdx.x) * V;
+    w += (b % G) * C;
     const bool ok = l0 < L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t base = (size_t)b * C * L + (ok ? l0 : 0);
@@ -662,7 +671,7 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
     }
     if (stages & 2) {
         const size_t lg = ((size_t)2 * GN + 4 * C * GN) * sizeof(float);
-        hipLaunchKernelGGL(hsm_fwd_gate, dim3(B, NGRP), dim3(256), lg, st, part_ms, part_acc, w_hz, w_out, D, state, h, C, T);
+        hipLaunchKernelGGL(hsm_fwd_gate, dim3(B, NGRP), dim3(256), lg, st, part_ms, part_acc, w_hz, w_out, D, state, h, C, T, 1);
         rc = kmu::launch_status("hsmssd_fwd gate");
         if (rc) return rc;
     }
@@ -681,7 +690,7 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
 template <int C>
 int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
                 const float* w_out, const float* D, const float* state, float* dx, float* p_bcdt, float* p_dw, float* p_hz,
-                float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st) {
+                float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st, int NG = 1) {
     int txA;
     const int TA = tiles_x3<C>(Hs, &txA);
     float* partA = ws;
@@ -699,20 +708,20 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
     const bool split_dx = !pb_x3 && passB_split(C, Hs) == 2;      // fp32 pass B at C = 64: two workgroups per tile add into dx
     int rc = 0;
     if (stages & 1) {
-        hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpk);
+        hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48, NG), dim3(256), 0, st, w_bcdt, w_dw, wpk);
 #ifdef KMU_EXPERIMENTAL_PASSB_X3
         hipLaunchKernelGGL(hsm_packT_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpkT);
 #endif
         rc = kmu::launch_status("hsmssd_bwd pack");
         if (rc) return rc;
         KMU_MAX_LDS(hsm_bwd_passA_x3<C>, la);
-        hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA);
+        hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA, NG);
         rc = kmu::launch_status("hsmssd_bwd passA (bf16x3)");
         if (rc) return rc;
     }
     if (stages & 2) {
         hipLaunchKernelGGL(hsm_bwd_gate, dim3(B, NGRP), dim3(256), lg, st, partA, dh, w_hz, w_out, D, state, dhp, delta, p_hz, p_out,
-                           p_D, split_dx ? dx : (float*)nullptr, C * Hs * Hs / 4, C, TA);
+                           p_D, split_dx ? dx : (float*)nullptr, C * Hs * Hs / 4, C, TA, NG);
         rc = kmu::launch_status("hsmssd_bwd gate");
         if (rc) return rc;
     }
@@ -734,7 +743,7 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
             const size_t lbf = lds_passB<C>();
             KMU_MAX_LDS(hsm_bwd_passB<C>, lbf);
             hipLaunchKernelGGL(hsm_bwd_passB<C>, dim3(TBF, B, passB_split(C, Hs)), dim3(TileForB<C>::NW * 64), lbf, st, x, dy, w_bcdt, w_dw,
-                               state, dhp, delta, dx, p_bcdt, p_dw, Hs, txF);
+                               state, dhp, delta, dx, p_bcdt, p_dw, Hs, txF, NG);
             rc = kmu::launch_status("hsmssd_bwd passB");
         }
     }
@@ -755,17 +764,20 @@ extern "C" size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs) {
 
 static int hsmssd_fwd_stages(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
                              const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
-                             size_t ws_bytes, int B, int C, int N, int Hs, int stages, kmu_stream_t stream, bool x3 = false) {
+                             size_t ws_bytes, int B, int C, int N, int Hs, int stages, kmu_stream_t stream, bool x3 = false,
+                             int groups = 1) {
     KMU_REQUIRE(x && w_bcdt && w_dw && w_hz && w_out && D && y && h && state && ws, "hsmssd_fwd: null pointer");
+    KMU_REQUIRE(groups >= 1 && (groups == 1 || x3) && B % groups == 0, "hsmssd_fwd: %d weight groups need the bf16x3 path and B %% groups == 0",
+                groups);
     KMU_REQUIRE(N == NS, "hsmssd_fwd: state_dim=%d unsupported (kernels are built for 64)", N);
     KMU_REQUIRE(C == 16 || C == 32 || C == 64, "hsmssd_fwd: C=%d unsupported (16/32/64)", C);
     KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0, "hsmssd_fwd: bad dims");
-    KMU_REQUIRE(ws_bytes >= kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs), "hsmssd_fwd: workspace too small");
+    KMU_REQUIRE(ws_bytes >= kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs) + (size_t)(groups - 1) * pack_x3_elems(C) * 2, "hsmssd_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (x3) {
-        if (C == 16) return fwd_impl_x3<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
-        if (C == 32) return fwd_impl_x3<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
-        return fwd_impl_x3<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
+        if (C == 16) return fwd_impl_x3<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups);
+        if (C == 32) return fwd_impl_x3<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups);
+        return fwd_impl_x3<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups);
     }
     if (C == 16) return fwd_impl<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
     if (C == 32) return fwd_impl<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
@@ -789,45 +801,60 @@ extern "C" int kmu_layernorm1d_partials(int B, int C, int L) {
     return B * kmu::cdiv(L, 256 * (V ? V : 1));
 }
 
-extern "C" int kmu_layernorm1d_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean,
-                                   int B, int C, int L, float eps, kmu_stream_t stream) {
+// groups > 1: x is [B/groups, groups*C, L] (= B samples of [C, L]); sample b is normalised with weight / bias rows b % groups of
+// the stacked [groups, C] parameters.  The weight-gradient partials keep their per-sample row order (kmu_layernorm1d_partials).
+extern "C" int kmu_layernorm1d_fwd_g(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean,
+                                     int B, int C, int L, float eps, int groups, kmu_stream_t stream) {
     KMU_REQUIRE(x && weight && bias && y && rstd_mean, "layernorm1d_fwd: null pointer");
-    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0, "layernorm1d_fwd: bad dims");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0 && groups >= 1 && B % groups == 0, "layernorm1d_fwd: bad dims");
+    const int G = groups;
     hipStream_t st = (hipStream_t)stream;
     const int V = ln1d_vf(C, L);
     const dim3 grid(kmu::cdiv(L, 256 * (V ? V : 1)), B);
     if (C == 16 && V == 4)
-        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<16, 4>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps);
+        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<16, 4>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps, G);
     else if (C == 32 && V == 2)
-        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<32, 2>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps);
+        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<32, 2>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps, G);
     else if (C == 64 && V == 1)
-        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<64, 1>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps);
+        hipLaunchKernelGGL((ln1d_fwd_reg_kernel<64, 1>), grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, L, eps, G);
     else
-        hipLaunchKernelGGL(ln1d_fwd_kernel, grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, C, L, eps);
+        hipLaunchKernelGGL(ln1d_fwd_kernel, grid, dim3(256), 0, st, x, weight, bias, y, rstd_mean, C, L, eps, G);
     return kmu::launch_status("layernorm1d_fwd");
 }
 
-extern "C" int kmu_layernorm1d_bwd(const float* x, const float* weight, const float* rstd_mean, const float* dy,
-                                   float* dx, float* d_weight_partial, float* d_bias_partial, int B, int C, int L,
-                                   kmu_stream_t stream) {
+extern "C" int kmu_layernorm1d_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd_mean,
+                                   int B, int C, int L, float eps, kmu_stream_t stream) {
+    return kmu_layernorm1d_fwd_g(x, weight, bias, y, rstd_mean, B, C, L, eps, 1, stream);
+}
+
+extern "C" int kmu_layernorm1d_bwd_g(const float* x, const float* weight, const float* rstd_mean, const float* dy,
+                                     float* dx, float* d_weight_partial, float* d_bias_partial, int B, int C, int L,
+                                     int groups, kmu_stream_t stream) {
     KMU_REQUIRE(x && weight && rstd_mean && dy && dx && d_weight_partial && d_bias_partial, "layernorm1d_bwd: null pointer");
-    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0, "layernorm1d_bwd: bad dims");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0 && groups >= 1 && B % groups == 0, "layernorm1d_bwd: bad dims");
+    const int G = groups;
     hipStream_t st = (hipStream_t)stream;
     const int V = ln1d_vb(C, L);
     const dim3 grid(kmu::cdiv(L, 256 * (V ? V : 1)), B);
     if (C == 16 && V == 2)
         hipLaunchKernelGGL((ln1d_bwd_reg_kernel<16, 2>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
-                           d_bias_partial, L);
+                           d_bias_partial, L, G);
     else if (C == 32 && V == 1)
         hipLaunchKernelGGL((ln1d_bwd_reg_kernel<32, 1>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
-                           d_bias_partial, L);
+                           d_bias_partial, L, G);
     else if (C == 64 && V == 1)
         hipLaunchKernelGGL((ln1d_bwd_reg_kernel<64, 1>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
-                           d_bias_partial, L);
+                           d_bias_partial, L, G);
     else
         hipLaunchKernelGGL(ln1d_bwd_kernel, grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial, d_bias_partial, C,
-                           L);
+                           L, G);
     return kmu::launch_status("layernorm1d_bwd");
+}
+
+extern "C" int kmu_layernorm1d_bwd(const float* x, const float* weight, const float* rstd_mean, const float* dy,
+                                   float* dx, float* d_weight_partial, float* d_bias_partial, int B, int C, int L,
+                                   kmu_stream_t stream) {
+    return kmu_layernorm1d_bwd_g(x, weight, rstd_mean, dy, dx, d_weight_partial, d_bias_partial, B, C, L, 1, stream);
 }
 
 extern "C" int kmu_hsmssd_fwd_stage_x3(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
@@ -835,6 +862,19 @@ extern "C" int kmu_hsmssd_fwd_stage_x3(const float* x, const float* w_bcdt, cons
                                        size_t ws_bytes, int B, int C, int N, int Hs, int stage, kmu_stream_t stream) {
     KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_fwd_stage_x3: stage must be 0 (pack + pass 1), 1 (gate) or 2 (pass 2)");
     return hsmssd_fwd_stages(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true);
+}
+
+// Grouped HSMSSD: x is [B, C, L] with B = samples x groups (a [B/groups, groups*C, L] tensor, the three direction branches of
+// EnhancedViMBlock stacked along the channel axis); sample b uses weight set b % groups of the stacked
+// w_bcdt [groups, 3N, C], w_dw [groups, 3N, 9], w_hz [groups, 2C, C], w_out [groups, C, C], D [groups].
+extern "C" size_t kmu_hsmssd_fwd_ws_bytes_g(int B, int C, int N, int Hs, int groups) {
+    return kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs) + (size_t)(groups > 1 ? groups - 1 : 0) * pack_x3_elems(C) * 2;
+}
+extern "C" int kmu_hsmssd_fwd_stage_x3_g(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                                         const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
+                                         size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_fwd_stage_x3_g: stage must be 0 (pack + pass 1), 1 (gate) or 2 (pass 2)");
+    return hsmssd_fwd_stages(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups);
 }
 
 // ---- backward entry points (kernels in hsmssd_bwd.inc) -------------------------------------------
@@ -866,25 +906,29 @@ static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, c
                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
-                             int Hs, int stages, kmu_stream_t stream, bool x3 = false) {
+                             int Hs, int stages, kmu_stream_t stream, bool x3 = false, int groups = 1) {
+    KMU_REQUIRE(groups >= 1 && (groups == 1 || x3) && B % groups == 0, "hsmssd_bwd: %d weight groups need the bf16x3 path and B %% groups == 0",
+                groups);
     KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial &&
                     d_w_hz_partial && d_w_out_partial && d_D_partial && ws,
                 "hsmssd_bwd: null pointer");
     KMU_REQUIRE(N == NS, "hsmssd_bwd: state_dim=%d unsupported (kernels are built for 64)", N);
     KMU_REQUIRE(C == 16 || C == 32 || C == 64, "hsmssd_bwd: C=%d unsupported (16/32/64)", C);
     KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0, "hsmssd_bwd: bad dims");
-    KMU_REQUIRE(ws_bytes >= (x3 ? kmu_hsmssd_bwd_ws_bytes_x3(B, C, N, Hs) : kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)), "hsmssd_bwd: workspace too small");
+    KMU_REQUIRE(ws_bytes >= (x3 ? kmu_hsmssd_bwd_ws_bytes_x3(B, C, N, Hs) + (size_t)(groups - 1) * pack_x3_elems(C) * 2
+                                : kmu_hsmssd_bwd_ws_bytes(B, C, N, Hs)),
+                "hsmssd_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* w = (float*)ws;
     if (x3) {
         if (C == 16)
             return bwd_impl_x3<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups);
         if (C == 32)
             return bwd_impl_x3<32>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups);
         return bwd_impl_x3<64>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st);
+                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups);
     }
     if (C == 16)
         return bwd_impl<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
@@ -912,6 +956,20 @@ extern "C" int kmu_hsmssd_bwd_stage_x3(const float* x, const float* dy, const fl
     KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_bwd_stage_x3: stage must be 0 (pack + pass A), 1 (gate) or 2 (pass B)");
     return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
                              d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true);
+}
+// grouped backward (see kmu_hsmssd_fwd_stage_x3_g).  The per-tile / per-sample weight-gradient partials keep their sample-major row
+// order: rows of sample b belong to weight group b % groups (the caller sums them per group).
+extern "C" size_t kmu_hsmssd_bwd_ws_bytes_x3_g(int B, int C, int N, int Hs, int groups) {
+    return kmu_hsmssd_bwd_ws_bytes_x3(B, C, N, Hs) + (size_t)(groups > 1 ? groups - 1 : 0) * pack_x3_elems(C) * 2;
+}
+extern "C" int kmu_hsmssd_bwd_stage_x3_g(const float* x, const float* dy, const float* dh, const float* w_bcdt,
+                                         const float* w_dw, const float* w_hz, const float* w_out, const float* D,
+                                         const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
+                                         float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, void* ws,
+                                         size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_bwd_stage_x3_g: stage must be 0 (pack + pass A), 1 (gate) or 2 (pass B)");
+    return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                             d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups);
 }
 extern "C" int kmu_hsmssd_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt,
                                     const float* w_dw, const float* w_hz, const float* w_out, const float* D,

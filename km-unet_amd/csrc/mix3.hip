@@ -14,17 +14,18 @@ constexpr int VPT = 4;   // float4s per thread => 4096 floats per 256-thread blo
 __global__ __launch_bounds__(256) void mix3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ f0,
                                                        const float* __restrict__ f1, const float* __restrict__ f2,
                                                        const float* __restrict__ g, const float* __restrict__ s, float* __restrict__ out,
-                                                       int n4) {
+                                                       int n4, int fs4) {
+    // fs4: per-sample stride of f0 / f1 / f2 in float4s (n4 for separate tensors, 3*n4 for channel slices of one [B,3C,H,W])
     const int b = blockIdx.y;
     const float sc = s ? s[b] : 1.f;
     const float k0 = sc * g[b * 3], k1 = sc * g[b * 3 + 1], k2 = sc * g[b * 3 + 2];
-    const size_t base = (size_t)b * n4;
+    const size_t base = (size_t)b * n4, fb = (size_t)b * fs4;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
         const int i = (blockIdx.x * VPT + v) * 256 + threadIdx.x;
         if (i >= n4) break;
-        const floatx4 xv = reinterpret_cast<const floatx4*>(x)[base + i], a = reinterpret_cast<const floatx4*>(f0)[base + i],
-                      bb = reinterpret_cast<const floatx4*>(f1)[base + i], c = reinterpret_cast<const floatx4*>(f2)[base + i];
+        const floatx4 xv = reinterpret_cast<const floatx4*>(x)[base + i], a = reinterpret_cast<const floatx4*>(f0)[fb + i],
+                      bb = reinterpret_cast<const floatx4*>(f1)[fb + i], c = reinterpret_cast<const floatx4*>(f2)[fb + i];
         reinterpret_cast<floatx4*>(out)[base + i] = xv + k0 * a + k1 * bb + k2 * c;
     }
 }
@@ -57,11 +58,11 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void mix3_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ g,
                                                              const float* __restrict__ s, const float* __restrict__ dpool,
                                                              float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
-                                                             int n4, int C, int HW4, float inv_hw) {
+                                                             int n4, int C, int HW4, float inv_hw, int fs4) {
     const int b = blockIdx.y;
     const float sc = s ? s[b] : 1.f;
     const float k0 = sc * g[b * 3], k1 = sc * g[b * 3 + 1], k2 = sc * g[b * 3 + 2];
-    const size_t base = (size_t)b * n4;
+    const size_t base = (size_t)b * n4, fb = (size_t)b * fs4;
     const float* dp = dpool + (size_t)b * 3 * C;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
@@ -69,9 +70,9 @@ __global__ __launch_bounds__(256) void mix3_bwd_apply_kernel(const float* __rest
         if (i >= n4) break;
         const int c = i / HW4;
         const floatx4 gy = reinterpret_cast<const floatx4*>(dy)[base + i];
-        reinterpret_cast<floatx4*>(d0)[base + i] = k0 * gy + dp[c] * inv_hw;
-        reinterpret_cast<floatx4*>(d1)[base + i] = k1 * gy + dp[C + c] * inv_hw;
-        reinterpret_cast<floatx4*>(d2)[base + i] = k2 * gy + dp[2 * C + c] * inv_hw;
+        reinterpret_cast<floatx4*>(d0)[fb + i] = k0 * gy + dp[c] * inv_hw;
+        reinterpret_cast<floatx4*>(d1)[fb + i] = k1 * gy + dp[C + c] * inv_hw;
+        reinterpret_cast<floatx4*>(d2)[fb + i] = k2 * gy + dp[2 * C + c] * inv_hw;
     }
 }
 
@@ -81,19 +82,19 @@ __global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ f1, const float* __restrict__ f2,
                                                        const float* __restrict__ g, const float* __restrict__ s, float* __restrict__ d0,
                                                        float* __restrict__ d1, float* __restrict__ d2, float* __restrict__ part, int n4,
-                                                       int B) {
+                                                       int B, int fs4) {
     __shared__ float red[4][3];
     const int b = blockIdx.y;
     const float sc = s ? s[b] : 1.f;
     const float k0 = sc * g[b * 3], k1 = sc * g[b * 3 + 1], k2 = sc * g[b * 3 + 2];
-    const size_t base = (size_t)b * n4;
+    const size_t base = (size_t)b * n4, fb = (size_t)b * fs4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
         const int i = (blockIdx.x * VPT + v) * 256 + threadIdx.x;
         if (i >= n4) break;
-        const floatx4 gy = reinterpret_cast<const floatx4*>(dy)[base + i], a = reinterpret_cast<const floatx4*>(f0)[base + i],
-                      bb = reinterpret_cast<const floatx4*>(f1)[base + i], c = reinterpret_cast<const floatx4*>(f2)[base + i];
+        const floatx4 gy = reinterpret_cast<const floatx4*>(dy)[base + i], a = reinterpret_cast<const floatx4*>(f0)[fb + i],
+                      bb = reinterpret_cast<const floatx4*>(f1)[fb + i], c = reinterpret_cast<const floatx4*>(f2)[fb + i];
         if (WRITE) {
             reinterpret_cast<floatx4*>(d0)[base + i] = k0 * gy;
             reinterpret_cast<floatx4*>(d1)[base + i] = k1 * gy;
@@ -125,7 +126,7 @@ extern "C" int kmu_mix3_fwd(const float* x, const float* f0, const float* f1, co
     KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_fwd: C*H*W = %d must be a positive multiple of 4",
                 n_per_sample);
     hipLaunchKernelGGL(mix3_fwd_kernel, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, x, f0, f1, f2, g, s, out,
-                       n_per_sample / 4);
+                       n_per_sample / 4, n_per_sample / 4);
     return kmu::launch_status("mix3_fwd");
 }
 
@@ -135,7 +136,7 @@ extern "C" int kmu_mix3_bwd(const float* dy, const float* f0, const float* f1, c
     KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_bwd: C*H*W = %d must be a positive multiple of 4",
                 n_per_sample);
     hipLaunchKernelGGL(mix3_bwd_kernel<true>, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, dy, f0, f1, f2, g, s, d_f0,
-                       d_f1, d_f2, d_g_partial, n_per_sample / 4, B);
+                       d_f1, d_f2, d_g_partial, n_per_sample / 4, B, n_per_sample / 4);
     return kmu::launch_status("mix3_bwd");
 }
 
@@ -158,7 +159,7 @@ extern "C" int kmu_mix3_bwd_dg(const float* dy, const float* f0, const float* f1
     KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_bwd_dg: C*H*W = %d must be a positive multiple of 4",
                 n_per_sample);
     hipLaunchKernelGGL(mix3_bwd_kernel<false>, dim3(kmu_mix3_blocks(n_per_sample), B), dim3(256), 0, (hipStream_t)stream, dy, f0, f1, f2, g, s,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, d_g_partial, n_per_sample / 4, B);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, d_g_partial, n_per_sample / 4, B, n_per_sample / 4);
     return kmu::launch_status("mix3_bwd_dg");
 }
 
@@ -168,6 +169,40 @@ extern "C" int kmu_mix3_bwd_apply(const float* dy, const float* g, const float* 
     KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0 && HW % 4 == 0, "mix3_bwd_apply: H*W = %d must be a positive multiple of 4", HW);
     const int n = C * HW;
     hipLaunchKernelGGL(mix3_bwd_apply_kernel, dim3(kmu_mix3_blocks(n), B), dim3(256), 0, (hipStream_t)stream, dy, g, s, d_pooled, d_f0, d_f1,
-                       d_f2, n / 4, C, HW / 4, 1.0f / (float)HW);
+                       d_f2, n / 4, C, HW / 4, 1.0f / (float)HW, n / 4);
     return kmu::launch_status("mix3_bwd_apply");
+}
+
+// ---- the same three kernels on channel slices of ONE stacked tensor F [B, 3C, H, W] (the grouped direction branches write
+// their outputs side by side): f_t = F + t*C*HW with a per-sample stride of 3*C*HW; d_f_t likewise into one stacked gradient.
+extern "C" int kmu_mix3_fwd_stacked(const float* x, const float* F, const float* g, const float* s, float* out, int B, int n_per_sample,
+                                    kmu_stream_t stream) {
+    KMU_REQUIRE(x && F && g && out, "mix3_fwd_stacked: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_fwd_stacked: C*H*W = %d must be a positive multiple of 4",
+                n_per_sample);
+    const int n = n_per_sample;
+    hipLaunchKernelGGL(mix3_fwd_kernel, dim3(kmu_mix3_blocks(n), B), dim3(256), 0, (hipStream_t)stream, x, F, F + n, F + 2 * (size_t)n, g, s,
+                       out, n / 4, 3 * (n / 4));
+    return kmu::launch_status("mix3_fwd_stacked");
+}
+
+extern "C" int kmu_mix3_bwd_dg_stacked(const float* dy, const float* F, const float* g, const float* s, float* d_g_partial, int B,
+                                       int n_per_sample, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && F && g && d_g_partial, "mix3_bwd_dg_stacked: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && n_per_sample > 0 && n_per_sample % 4 == 0, "mix3_bwd_dg_stacked: C*H*W = %d must be a positive multiple of 4",
+                n_per_sample);
+    const int n = n_per_sample;
+    hipLaunchKernelGGL(mix3_bwd_kernel<false>, dim3(kmu_mix3_blocks(n), B), dim3(256), 0, (hipStream_t)stream, dy, F, F + n, F + 2 * (size_t)n,
+                       g, s, (float*)nullptr, (float*)nullptr, (float*)nullptr, d_g_partial, n / 4, B, 3 * (n / 4));
+    return kmu::launch_status("mix3_bwd_dg_stacked");
+}
+
+extern "C" int kmu_mix3_bwd_apply_stacked(const float* dy, const float* g, const float* s, const float* d_pooled, float* dF, int B, int C,
+                                          int HW, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && g && d_pooled && dF, "mix3_bwd_apply_stacked: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0 && HW % 4 == 0, "mix3_bwd_apply_stacked: H*W = %d must be a positive multiple of 4", HW);
+    const int n = C * HW;
+    hipLaunchKernelGGL(mix3_bwd_apply_kernel, dim3(kmu_mix3_blocks(n), B), dim3(256), 0, (hipStream_t)stream, dy, g, s, d_pooled, dF, dF + n,
+                       dF + 2 * (size_t)n, n / 4, C, HW / 4, 1.0f / (float)HW, 3 * (n / 4));
+    return kmu::launch_status("mix3_bwd_apply_stacked");
 }

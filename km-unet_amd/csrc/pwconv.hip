@@ -42,7 +42,9 @@ template <int NT>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w, long w_sn,
                                                       long w_sk, const float* __restrict__ bias,
                                                       const float* __restrict__ mul_pre, const float* __restrict__ addend,
-                                                      float* __restrict__ y, int K, int N, int P, int act_in) {
+                                                      float* __restrict__ y, int K, int N, int P, int act_in, int G, long w_sg) {
+    // G > 1: grouped convolution (block-diagonal weights): x has G*K channels, y has N = G*Ng channels, tile n0 belongs to group
+    // n0 / Ng and contracts that group's K input channels with w + g*w_sg indexed by the LOCAL output channel
     extern __shared__ float wl[];
     constexpr int S = (16 * NT) % 32 == 16 ? 16 * NT : 16 * NT + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,10 +52,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     const int bpp = (P + 255) / 256;
     const int b = blockIdx.x / bpp, p0 = (blockIdx.x % bpp) * 256 + wave * 64;
     const int n0 = blockIdx.y * 16 * NT;
+    const int Ng = N / G, g = n0 / Ng, nl0 = n0 - g * Ng;
+    w += (long)g * w_sg;
 
     // this wave's first x chunk is requested BEFORE the weights are staged: the two round trips (x from HBM, W from L2 + the
     // barrier) then overlap instead of queueing behind each other in every (short-lived) workgroup
-    const float* xb = x + (size_t)b * K * P + p0 + 4 * ((m >> 2) + 4 * (m & 3));
+    const float* xb = x + ((size_t)b * G + g) * K * P + p0 + 4 * ((m >> 2) + 4 * (m & 3));
     floatx4 xv[4], xn[4];
     if (p0 < P) {
 #pragma unroll
@@ -63,12 +67,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     if (w_sk == 1) {
         for (int e = tid; e < 16 * NT * K; e += 256) {
             const int n = e / K, k = e - n * K;
-            wl[k * S + n] = w[(long)(n0 + n) * w_sn + k];
+            wl[k * S + n] = w[(long)(nl0 + n) * w_sn + k];
         }
     } else {
         for (int e = tid; e < 16 * NT * K; e += 256) {
             const int k = e / (16 * NT), n = e - k * 16 * NT;
-            wl[k * S + n] = w[(long)(n0 + n) * w_sn + (long)k * w_sk];
+            wl[k * S + n] = w[(long)(nl0 + n) * w_sn + (long)k * w_sk];
         }
     }
     __syncthreads();
@@ -133,18 +137,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
 // through LDS (fixed order) and the workgroup dumps slab[sp][g][mt][nt][lane] (float4 per lane).
 template <int MT, int NT>
 __device__ __forceinline__ void wgrad_load(floatx4 (&a)[MT][2], floatx4 (&bx)[NT][2], const float* __restrict__ x,
-                                           const float* __restrict__ gy, int ch, int cpp, int Ci, int Co, int P, int co0, int ci0,
+                                           const float* __restrict__ gy, int ch, int cpp, int XC, int GC, int P, int co0, int ci0,
                                            int r, int q) {
+    // XC / GC: channel counts of the TENSORS x / gy (their batch strides; > Ci / Co when one group of a grouped conv is contracted)
     const int b = ch / cpp, p0 = (ch - b * cpp) * 32 + 8 * q;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const float* g = gy + ((size_t)b * Co + co0 + 16 * mt + r) * P + p0;
+        const float* g = gy + ((size_t)b * GC + co0 + 16 * mt + r) * P + p0;
         a[mt][0] = *reinterpret_cast<const floatx4*>(g);
         a[mt][1] = *reinterpret_cast<const floatx4*>(g + 4);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float* xp = x + ((size_t)b * Ci + ci0 + 16 * nt + r) * P + p0;
+        const float* xp = x + ((size_t)b * XC + ci0 + 16 * nt + r) * P + p0;
         bx[nt][0] = *reinterpret_cast<const floatx4*>(xp);
         bx[nt][1] = *reinterpret_cast<const floatx4*>(xp + 4);
     }
@@ -153,7 +158,7 @@ __device__ __forceinline__ void wgrad_load(floatx4 (&a)[MT][2], floatx4 (&bx)[NT
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                        float* __restrict__ slab, float* __restrict__ bslab, int Ci, int Co,
-                                                       int P, int nchunks, int act_in) {
+                                                       int P, int nchunks, int act_in, int XC, int GC) {
     __shared__ floatx4 red[3][MT * NT][64];
     __shared__ float bred[3][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,10 +177,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
     floatx4 a[MT][2], bx[NT][2], an[MT][2], bn[NT][2];
-    if (gw < nchunks) wgrad_load<MT, NT>(a, bx, x, gy, gw, cpp, Ci, Co, P, co0, ci0, r, q);
+    if (gw < nchunks) wgrad_load<MT, NT>(a, bx, x, gy, gw, cpp, XC, GC, P, co0, ci0, r, q);
     for (int ch = gw; ch < nchunks; ch += nw) {
         const bool more = ch + nw < nchunks;
-        if (more) wgrad_load<MT, NT>(an, bn, x, gy, ch + nw, cpp, Ci, Co, P, co0, ci0, r, q);
+        if (more) wgrad_load<MT, NT>(an, bn, x, gy, ch + nw, cpp, XC, GC, P, co0, ci0, r, q);
         if (act_in) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -302,50 +307,52 @@ inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
 
 template <int NT>
 int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, const float* addend,
-                float* y, int B, int K, int N, int P, int act_in, hipStream_t st) {
+                float* y, int B, int K, int N, int P, int act_in, hipStream_t st, int G, long w_sg) {
     const size_t lds = (size_t)K * lds_stride(NT) * sizeof(float);
     KMU_MAX_LDS((pw_gemm_kernel<NT>), lds);
     hipLaunchKernelGGL((pw_gemm_kernel<NT>), dim3(B * ((P + 255) / 256), N / (16 * NT)), dim3(256), lds, st, x, w, w_sn, w_sk, bias,
-                       mul_pre, addend, y, K, N, P, act_in);
+                       mul_pre, addend, y, K, N, P, act_in, G, w_sg);
     return 0;
 }
 
 int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y,
-         int B, int K, int N, int P, int act_in, hipStream_t st, const float* addend = nullptr) {
+         int B, int K, int N, int P, int act_in, hipStream_t st, const float* addend = nullptr, int G = 1, long w_sg = 0) {
+    // K = contraction channels PER GROUP, N = output channels in total (G groups of N / G)
     KMU_REQUIRE(B > 0 && K > 0 && N > 0 && K % 16 == 0 && N % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16",
                 what, K, N);
+    KMU_REQUIRE(G >= 1 && N % (16 * G) == 0, "%s: %d output channels do not split into %d groups of whole 16-channel tiles", what, N, G);
     KMU_REQUIRE(P > 0 && P % 64 == 0, "%s: H*W = %d must be a positive multiple of 64", what, P);
     KMU_REQUIRE(K <= 256, "%s: %d contraction channels exceed the LDS weight tile (256)", what, K);
     // With few pixel blocks (the 32x32 level: B*P/256 = 32) a 4-tile-wide workgroup leaves most of the 256 CUs idle and walks all K
     // channels on its own: 27.6 us for 256 -> 64 at [8, ., 32, 32] (0.38 TB/s).  Narrower channel tiles there give grid.y more
     // workgroups; x is re-read from L2 once per channel tile, which at these sizes (<= 8 MB) is cheaper than an idle device.
-    int nt = pick_tiles(N / 16);
+    int nt = pick_tiles(N / G / 16);
     const long blocks_x = (long)B * ((P + 255) / 256);
     while (nt > 1 && blocks_x * (N / (16 * nt)) < 192) nt = (nt == 4) ? 2 : 1;
     switch (nt) {
-        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
-        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
-        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
-        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st); break;
+        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
+        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
+        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
+        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
     }
     return kmu::launch_status(what);
 }
 
 template <int MT, int NT>
 void launch_wgrad(const WgradPlan& pl, const float* x, const float* gy, float* slab, float* bslab, int Ci, int Co, int P, int act_in,
-                  hipStream_t st) {
+                  hipStream_t st, int XC, int GC) {
     hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), dim3(pl.G, pl.nsp), dim3(256), 0, st, x, gy, slab, bslab, Ci, Co, P, pl.nchunks,
-                       act_in);
+                       act_in, XC, GC);
 }
 
 template <int MT>
 void launch_wgrad_nt(const WgradPlan& pl, const float* x, const float* gy, float* slab, float* bslab, int Ci, int Co, int P,
-                     int act_in, hipStream_t st) {
+                     int act_in, hipStream_t st, int XC, int GC) {
     switch (pl.NT) {
-        case 4: launch_wgrad<MT, 4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
-        case 3: launch_wgrad<MT, 3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
-        case 2: launch_wgrad<MT, 2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
-        default: launch_wgrad<MT, 1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        case 4: launch_wgrad<MT, 4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        case 3: launch_wgrad<MT, 3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        case 2: launch_wgrad<MT, 2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        default: launch_wgrad<MT, 1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
     }
 }
 
@@ -377,28 +384,60 @@ extern "C" size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P) {
     return (pl.slab_floats + pl.bslab_floats) * sizeof(float);
 }
 
-extern "C" int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci,
-                                     int Co, int P, int act_in, kmu_stream_t stream) {
-    KMU_REQUIRE(x && gy && dw && ws, "pwconv_bwd_weight: null pointer");
-    KMU_REQUIRE(B > 0 && Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0,
-                "pwconv_bwd_weight: channels (%d -> %d) must be positive multiples of 16", Ci, Co);
-    KMU_REQUIRE(P > 0 && P % 32 == 0, "pwconv_bwd_weight: H*W = %d must be a positive multiple of 32", P);
+static int pw_bwd_weight(const char* what, const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B,
+                        int Ci, int Co, int P, int act_in, hipStream_t st, int XC, int GC) {
+    KMU_REQUIRE(x && gy && dw && ws, "%s: null pointer", what);
+    KMU_REQUIRE(B > 0 && Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16", what,
+                Ci, Co);
+    KMU_REQUIRE(P > 0 && P % 32 == 0, "%s: H*W = %d must be a positive multiple of 32", what, P);
     const WgradPlan pl = wgrad_plan(B, Ci, Co, P);
-    KMU_REQUIRE(ws_bytes >= (pl.slab_floats + pl.bslab_floats) * sizeof(float), "pwconv_bwd_weight: workspace too small (%zu < %zu)",
-                ws_bytes, (pl.slab_floats + pl.bslab_floats) * sizeof(float));
+    KMU_REQUIRE(ws_bytes >= (pl.slab_floats + pl.bslab_floats) * sizeof(float), "%s: workspace too small (%zu < %zu)", what, ws_bytes,
+                (pl.slab_floats + pl.bslab_floats) * sizeof(float));
     float* slab = (float*)ws;
     float* bslab = dbias ? slab + pl.slab_floats : nullptr;
-    hipStream_t st = (hipStream_t)stream;
     switch (pl.MT) {
-        case 4: launch_wgrad_nt<4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
-        case 3: launch_wgrad_nt<3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
-        case 2: launch_wgrad_nt<2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
-        default: launch_wgrad_nt<1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st); break;
+        case 4: launch_wgrad_nt<4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        case 3: launch_wgrad_nt<3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        case 2: launch_wgrad_nt<2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        default: launch_wgrad_nt<1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
     }
-    int rc = kmu::launch_status("pwconv_bwd_weight");
+    int rc = kmu::launch_status(what);
     if (rc) return rc;
     const int wblocks = pl.nsp * pl.MT * pl.NT * 64 / 16, bblocks = dbias ? Co / 16 : 0;
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, slab, bslab, dw, dbias, Ci, Co, pl.MT, pl.NT,
                        pl.G, wblocks);
-    return kmu::launch_status("pwconv_bwd_weight(reduce)");
+    return kmu::launch_status(what);
+}
+
+extern "C" int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci,
+                                     int Co, int P, int act_in, kmu_stream_t stream) {
+    return pw_bwd_weight("pwconv_bwd_weight", x, gy, dw, dbias, ws, ws_bytes, B, Ci, Co, P, act_in, (hipStream_t)stream, Ci, Co);
+}
+
+// ---- grouped 1x1 convolution (block-diagonal weights): x [B, G*Ci, P] -> y [B, G*Co, P], w [G*Co, Ci], bias [G*Co] ----------
+// The three direction branches of EnhancedViMBlock (KM_UNetV3_SH.py:99-101,137-139) run the SAME layer sequence on tensors of the
+// same shape with their own weights: stacked along the channel axis they are one launch per layer instead of three -- at the
+// 64x64 / 32x32 levels every launch is latency-bound, so three times the workgroups cost almost nothing.
+extern "C" int kmu_pwconv_fwd_g(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int P, int act_in,
+                                int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(x && w && y && groups >= 1, "pwconv_fwd_g: null pointer / groups < 1");
+    return gemm("pwconv_fwd_g", x, w, Ci, 1, bias, nullptr, y, B, Ci, groups * Co, P, act_in, (hipStream_t)stream, nullptr, groups,
+                (long)Co * Ci);
+}
+
+extern "C" int kmu_pwconv_bwd_input_g(const float* gy, const float* w, const float* x_pre, const float* addend, float* dx, int B, int Ci,
+                                      int Co, int P, int act_in, int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(gy && w && dx && groups >= 1, "pwconv_bwd_input_g: null pointer / groups < 1");
+    KMU_REQUIRE(!act_in || x_pre, "pwconv_bwd_input_g: act_in needs the pre-activation input");
+    return gemm("pwconv_bwd_input_g", gy, w, 1, Ci, nullptr, act_in ? x_pre : nullptr, dx, B, Co, groups * Ci, P, 0, (hipStream_t)stream,
+                addend, groups, (long)Co * Ci);
+}
+
+// weight gradient of group g of the grouped conv (dw [Co, Ci] and dbias [Co] of THAT group); one call per group -- these kernels
+// run off the activation-gradient chain (ops._wgrad), where their launch count does not matter
+extern "C" int kmu_pwconv_bwd_weight_g(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci,
+                                       int Co, int P, int act_in, int groups, int g, kmu_stream_t stream) {
+    KMU_REQUIRE(groups >= 1 && g >= 0 && g < groups, "pwconv_bwd_weight_g: group %d of %d", g, groups);
+    return pw_bwd_weight("pwconv_bwd_weight_g", x + (size_t)g * Ci * P, gy + (size_t)g * Co * P, dw, dbias, ws, ws_bytes, B, Ci, Co, P,
+                         act_in, (hipStream_t)stream, groups * Ci, groups * Co);
 }

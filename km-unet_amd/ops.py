@@ -89,8 +89,9 @@ _WG_BUSY = set()
 def _leaf(*ts):
     """True when every given tensor is a leaf (a parameter handed to the op as it is).  Only then may its gradient be filled in
     later: a weight that reaches the op through autograd operations (conv3tap's permuted taps, TripleNorm's summed affine
-    parameters) has its gradient READ by those operations' backward right after the node returns."""
-    return all(t is None or t.grad_fn is None for t in ts)
+    parameters) has its gradient READ by those operations' backward right after the node returns.  grouped.StackParamsFn is the
+    exception: its backward only slices the stacked gradient into views."""
+    return all(t is None or t.grad_fn is None or type(t.grad_fn).__name__ == "StackParamsFnBackward" for t in ts)
 
 
 def _wgrad(job, defer=True):
