@@ -80,6 +80,26 @@ def live_parameters(model, example_input, loss_fn=None):
     return live
 
 
+def branch_adjacent_order(model, params):
+    """The same parameters, reordered so that the corresponding tensors of EnhancedViMBlock's height / width / channel branches
+    sit next to each other: FlatGradBucket.flatten_parameters then lays them back to back in the flat buffer, and the stacked
+    branch pass (grouped.py) views each triple as one [3, ...] tensor without copying."""
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    tags = ("height_block.", "width_block.", "channel_block.")
+    first, keyed = {}, []
+    for idx, p in enumerate(params):
+        name, br = name_of.get(id(p), "#%d" % idx), 0
+        key = name
+        for bi, t in enumerate(tags):
+            if t in name:
+                key, br = name.replace(t, "@."), bi
+                break
+        first.setdefault(key, idx)
+        keyed.append((first[key], br, idx, p))
+    keyed.sort(key=lambda t: t[:3])
+    return [t[3] for t in keyed]
+
+
 class DataParallel:
     """Minimal DDP: broadcast parameters/buffers from rank 0, average gradients after backward."""
 
@@ -94,7 +114,7 @@ class DataParallel:
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
                     dist.broadcast(t.data, src=0, group=process_group)
-        self.bucket = FlatGradBucket(live_params)
+        self.bucket = FlatGradBucket(branch_adjacent_order(model, live_params))
 
     def zero_grad(self):
         self.bucket.zero_()

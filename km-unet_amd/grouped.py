@@ -251,7 +251,7 @@ class FfnBlendGFn(torch.autograd.Function):
         hid, C = w1.shape[0] // G, w1.shape[1]
         w1c, w2c = _f32c(w1, "fc1 weight").view(G * hid, C), _f32c(w2, "fc2 weight").view(G * C, hid)
         z1 = _pw_fwd_g(lib, x, w1c, None, C, hid)
-        h, st1 = ops._k_bn_fwd(lib, z1, None, g1, b1, None, rm1, rv1, mom1, eps1, 1, training, None)
+        h, st1 = ops._k_bn_fwd(lib, z1, None, g1, b1, None, rm1, rv1, mom1, eps1, 1, training, None, tap_groups=G)
         z2 = _pw_fwd_g(lib, h, w2c, None, hid, C)
         out, st2 = ops._k_bn_fwd(lib, z2, x, g2, b2, a_row, rm2, rv2, mom2, eps2, 0, training, None)
         ctx.save_for_backward(x, w1c, z1, st1, h, w2c, z2, st2, g1, b1, g2, b2, a_row)

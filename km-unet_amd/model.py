@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import grouped, ops
 from .nn import DAGEM, DySample, EfficientViMBlock, IntelligentWaveletPoolingModule, KANConv2d, _TORCH_GLUE, conv1x1, conv3x3, gate_mlp, group_norm
 
 
@@ -24,6 +24,14 @@ import os as _os
 # (34.1 vs 30.6 ms/step); inside the captured hipGraph the branches become parallel graph branches and their small kernels
 # overlap: 17.16 vs 17.91 ms/step (round 2, B=8).  On by default; KMU_BRANCH_STREAMS=0 serialises them again.
 _BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") == "1"
+# KMU_GROUPED_BRANCHES=1: the three direction branches stacked along the channel axis, one launch per layer (grouped.py), instead of
+# three passes on side streams.  Measured on MI355X (B = 8, round 2): 1380 instead of 1837 launches and 14.4 instead of 17.7 ms of
+# serialised kernel time per step -- but 13.5 ms/step against 12.9 for the forked branches (grouped only at C >= 32: 13.0, C >= 64:
+# 12.96): the stacked kernels fill the device, so the weight-gradient / pyramid side streams no longer find idle CUs to overlap
+# into, while the three forked branches already overlap each other well.  Kept as a tested option (a single-stream runtime, or a
+# larger batch where the forks stop paying, would prefer it); off by default.
+_GROUPED_BRANCHES = _os.environ.get("KMU_GROUPED_BRANCHES", "0") == "1"
+_GROUPED_MIN_C = int(_os.environ.get("KMU_GROUPED_MIN_C", "0"))
 _SIDE = {}
 
 
@@ -157,14 +165,15 @@ class DirectionViM(nn.Module):
         self.proj = nn.Conv2d(dim, dim, kshape[0], padding=kshape[1])
         self.attn = DirectionAttention(dim, mode)
 
-    def forward(self, x):
+    def project(self, x):
         if self.mode == "channel":
-            x = conv1x1(x, self.proj)
-        elif "conv3tap" not in _TORCH_GLUE and ops.pwconv_supported(3 * x.shape[1], self.proj.out_channels, x.shape[2] * x.shape[3]):
-            x = ops.conv3tap(x, self.proj.weight, self.proj.bias, 0 if self.mode == "height" else 1)
-        else:
-            x = self.proj(x)
-        return self.attn(self.vit_mamba(x))
+            return conv1x1(x, self.proj)
+        if "conv3tap" not in _TORCH_GLUE and ops.pwconv_supported(3 * x.shape[1], self.proj.out_channels, x.shape[2] * x.shape[3]):
+            return ops.conv3tap(x, self.proj.weight, self.proj.bias, 0 if self.mode == "height" else 1)
+        return self.proj(x)
+
+    def forward(self, x):
+        return self.attn(self.vit_mamba(self.project(x)))
 
 
 class TripleNorm(nn.Module):
@@ -226,8 +235,17 @@ class EnhancedViMBlock(nn.Module):
         return feats
 
     def forward(self, x):
-        feats = self._branches(x)
         dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
+        blocks = (self.height_block, self.width_block, self.channel_block)
+        if _GROUPED_BRANCHES and x.shape[1] >= _GROUPED_MIN_C and not _TORCH_GLUE and (x.shape[2] * x.shape[3]) % 4 == 0 \
+                and grouped.supported(blocks, x):
+            # the three branches as ONE stacked pass: every layer a single launch on [B, 3C, H, W] (km-unet_amd/grouped.py)
+            F3 = grouped.direction_branches(blocks, [b.project(x) for b in blocks])
+            fg = self.fusion_gate
+            x = grouped.GatedMix3StackedFn.apply(x, F3, fg[1].weight, fg[1].bias, fg[3].weight, fg[3].bias,
+                                                 dp.scale(x) if dp is not None else None)
+            return self._ffn(x, dp)
+        feats = self._branches(x)
         if x.is_cuda and "mix3" not in _TORCH_GLUE and "gate_mlp" not in _TORCH_GLUE and (x.shape[2] * x.shape[3]) % 4 == 0:
             # pool -> gate MLP -> softmax -> weighted branch sum + DropPath + residual as one autograd node
             x = ops.gated_mix3(x, feats[0], feats[1], feats[2], self.fusion_gate[1], self.fusion_gate[3],

@@ -49,9 +49,12 @@ def _call(key, fn, *args):
 RELU_TAP = None
 
 
-def _tap_relu(t):
+def _tap_relu(t, groups=1):
+    """groups > 1: t stacks the outputs of `groups` reference modules along the channel axis (grouped.py); the reference runs them
+    one after the other, so their masks are reported separately, in that order."""
     if RELU_TAP is not None:
-        RELU_TAP.append((t.detach() > 0).cpu())
+        for part in (t.detach() > 0).cpu().chunk(groups, dim=1):
+            RELU_TAP.append(part)
 
 
 def _f32c(t, name):
@@ -1013,7 +1016,7 @@ def bn_blend(t, x=None, bn=None, alpha=None, row=0, relu=False):
 # As separate autograd nodes, x receives two full-size gradients (through f and through the blend) that the engine sums
 # with one `add` kernel per stage (45 per step for these two stage types); here the last backward kernel of the f branch
 # (depthwise backward-data / fc1's input gradient) adds the blend gradient in its epilogue.
-def _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, relu, training, nbt):
+def _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, relu, training, nbt, tap_groups=1):
     B, C = t.shape[:2]
     HW = t.numel() // (B * C)
     out = torch.empty_like(t)
@@ -1024,7 +1027,7 @@ def _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, relu, traini
                      _ptr(rv), float(momentum), float(eps), int(relu), int(training), _ptr(out), _ptr(stats), _ptr(ws), _ptr(nbt), B, C, HW,
                      _stream()), "kmu_bn_blend_fwd")
     if relu and a_row is None:
-        _tap_relu(out)
+        _tap_relu(out, tap_groups)
     return out, stats
 
 

@@ -119,7 +119,8 @@ def test_dp_world2_real_parameter_structure():
     net = fill_parameters(Oracle(num_classes=5), 20).eval()
     data = torch.rand(2, 10, 1, 16, 16, generator=torch.Generator().manual_seed(9)).squeeze(2)
     torch.nn.functional.mse_loss(net(data[:, :5]), data[:, 5:]).backward()
-    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None])
+    from km_unet_amd.dp import branch_adjacent_order     # the bucket keeps the three direction branches' tensors adjacent
+    ref = torch.cat([p.grad.reshape(-1) for p in branch_adjacent_order(net, [p for p in net.parameters() if p.grad is not None])])
     assert ref.numel() == ret["numel"]
     err = (ret["grads"] - ref).abs().max().item() / ref.abs().max().item()
     assert err < 1e-5, err

@@ -301,3 +301,44 @@ def test_wgrad_side_streams_match_serial(monkeypatch):
     e1, e2 = (g1 - g0).abs().max().item() / scale, (g2 - g0).abs().max().item() / scale
     print("  [wgrad side streams] flat-gradient difference vs serial %.2e / %.2e of the largest gradient" % (e1, e2))
     assert e1 < 1e-5 and e2 < 1e-5
+
+
+@pytest.mark.parametrize("C,hw", [(16, 32), (32, 16), (64, 16)])
+def test_grouped_branches_match_separate(monkeypatch, C, hw):
+    """EnhancedViMBlock with the three direction branches as ONE stacked pass (km-unet_amd/grouped.py: grouped pointwise convs,
+    LayerNorm1D, HSMSSD, gate MLP; per-channel layers on 3C channels) against the three separate passes through the same
+    kernels: same arithmetic per element => output and every parameter gradient agree to rounding (train mode, batch-statistics
+    BatchNorm included; running statistics compared too)."""
+    import copy
+    import km_unet_amd
+    from km_unet_amd import model as M
+    torch.manual_seed(C)
+    blk = M.EnhancedViMBlock(C, state_dim=16, drop_path=0.0).cuda().train()
+    with torch.no_grad():
+        for n, p in blk.named_parameters():         # away from the zero-initialised BatchNorm weights / 1e-4 alphas
+            if p.dim() <= 1 or "alpha" in n:
+                p.copy_(torch.randn_like(p) * 0.5 + (1.0 if n.endswith("norm.weight") else 0.0))
+    blks = {False: blk, True: copy.deepcopy(blk)}
+    x = torch.randn(4, C, hw, hw, device="cuda")
+    gy = torch.randn(4, C, hw, hw, device="cuda")
+    res = {}
+    for flag in (False, True):
+        monkeypatch.setattr(M, "_GROUPED_BRANCHES", flag)
+        b = blks[flag]
+        xi = x.clone().requires_grad_(True)
+        y = b(xi)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        res[flag] = (y.detach(), xi.grad, {k: p.grad for k, p in b.named_parameters() if p.grad is not None},
+                     {k: v.clone() for k, v in b.named_buffers() if v.dtype.is_floating_point})
+    e_y, e_dx = rel_err(res[True][0], res[False][0]), rel_err(res[True][1], res[False][1])
+    assert sorted(res[True][2]) == sorted(res[False][2])
+    gmax = max(v.abs().max().item() for v in res[False][2].values())
+    worst = ("", 0.0)
+    for k, v in res[False][2].items():
+        e = (res[True][2][k] - v).abs().max().item() / max(v.abs().max().item(), 1e-4 * gmax)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    e_buf = max(rel_err(res[True][3][k], v) for k, v in res[False][3].items())
+    print("  [grouped branches C=%d %dx%d] y=%.2e dx=%.2e worst parameter gradient %.2e (%s) running stats %.2e" % (
+        C, hw, hw, e_y, e_dx, worst[1], worst[0], e_buf))
+    assert e_y < 1e-5 and e_dx < 1e-4 and worst[1] < 1e-4 and e_buf < 1e-5
