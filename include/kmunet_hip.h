@@ -448,6 +448,31 @@ int kmu_contingency_counts(const float* pred, const float* target, unsigned long
                            const int* thresholds, int n_thresholds, float scale, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * TripleNorm (KM_UNetV3_SH.py:266-284): y = (GroupNorm_h(x) + GroupNorm_w(x) + LayerNorm_c(x)) / 3 on x [B,C,HW], C in {16,32,64}.
+ * norm_h / norm_w = nn.GroupNorm(1, C) share their statistics (one group: invariant under the H/W transpose of the 'height' branch);
+ * norm_c = nn.LayerNorm(C) on the channels-last view = per-pixel statistics over C.
+ *   fwd: stats [B,2] = (mean, rstd) of each sample for the backward; ws: B*C*kmu_triple_norm_splits(HW)*2 floats
+ *   bwd: dx = addend (or 0 when NULL) + d loss / d x;  d_gsum_partial [B,C] = per-sample d(gh) = d(gw),
+ *        d_bsum_partial [B,C] = per-sample d(bh) = d(bw) = d(bc), d_gc_partial [kmu_triple_norm_partials(B,C,HW), C]: column sums
+ *        (kmu_colsum_multi) give the parameter gradients; ws as in fwd
+ * kmu_pwconv_fwd_res / kmu_pwconv_bwd_input_s: the 1x1 convs of EnhancedViMBlock's FFN tail with the residual and DropPath's
+ * per-sample factor folded in (:147-150): y = addend + s[b] (W act(x) + bias);  dx = s[b] (W^T gy) act'(x_pre); s may be NULL.
+ * ------------------------------------------------------------------------------------ */
+int kmu_triple_norm_supported(int C, int HW);
+int kmu_triple_norm_splits(int HW);
+int kmu_triple_norm_partials(int B, int C, int HW);
+int kmu_triple_norm_fwd(const float* x, const float* gh, const float* bh, const float* gw, const float* bw, const float* gc,
+                        const float* bc, float* y, float* stats, float* ws, int B, int C, int HW, float eps_gn, float eps_ln,
+                        kmu_stream_t stream);
+int kmu_triple_norm_bwd(const float* x, const float* dy, const float* gh, const float* gw, const float* gc, const float* stats,
+                        const float* addend, float* dx, float* d_gsum_partial, float* d_bsum_partial, float* d_gc_partial, float* ws,
+                        int B, int C, int HW, float eps_ln, kmu_stream_t stream);
+int kmu_pwconv_fwd_res(const float* x, const float* w, const float* bias, const float* addend, const float* bscale, float* y, int B,
+                       int Ci, int Co, int P, int act_in, kmu_stream_t stream);
+int kmu_pwconv_bwd_input_s(const float* gy, const float* w, const float* x_pre, const float* bscale, float* dx, int B, int Ci, int Co,
+                           int P, int act_in, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Grouped variants.  EnhancedViMBlock (KM_UNetV3_SH.py:97-151) runs three DirectionViM branches (height / width / channel,
  * :154-212) that differ only in their first projection: afterwards each applies the SAME layer sequence (EfficientViMBlock,
  * efficient_vim_init.py:64-97, then DirectionAttention, :215-263) to a tensor of the same shape with its own weights.

@@ -123,6 +123,13 @@ SIGNATURES = {
     "kmu_mix3_fwd_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),
     "kmu_mix3_bwd_dg_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),
     "kmu_mix3_bwd_apply_stacked": (_I, [_P] * 5 + [_I] * 3 + [_P]),
+    "kmu_triple_norm_supported": (_I, [_I, _I]),
+    "kmu_triple_norm_splits": (_I, [_I]),
+    "kmu_triple_norm_partials": (_I, [_I, _I, _I]),
+    "kmu_triple_norm_fwd": (_I, [_P] * 10 + [_I] * 3 + [_c.c_float, _c.c_float, _P]),
+    "kmu_triple_norm_bwd": (_I, [_P] * 12 + [_I] * 3 + [_c.c_float, _P]),
+    "kmu_pwconv_fwd_res": (_I, [_P] * 6 + [_I] * 5 + [_P]),
+    "kmu_pwconv_bwd_input_s": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 

@@ -37,6 +37,7 @@ SOURCES = [
     ("contingency.hip", []),
     ("conv3x3_x3.hip", []),
     ("resize.hip", []),
+    ("triple_norm.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

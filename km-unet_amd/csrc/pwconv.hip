@@ -42,7 +42,8 @@ template <int NT>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w, long w_sn,
                                                       long w_sk, const float* __restrict__ bias,
                                                       const float* __restrict__ mul_pre, const float* __restrict__ addend,
-                                                      float* __restrict__ y, int K, int N, int P, int act_in, int G, long w_sg) {
+                                                      float* __restrict__ y, int K, int N, int P, int act_in, int G, long w_sg,
+                                                      const float* __restrict__ bscale) {
     // G > 1: grouped convolution (block-diagonal weights): x has G*K channels, y has N = G*Ng channels, tile n0 belongs to group
     // n0 / Ng and contracts that group's K input channels with w + g*w_sg indexed by the LOCAL output channel
     extern __shared__ float wl[];
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + 16 * nt + m;
         const float bv = bias ? bias[n] : 0.f;
+        const float sc = bscale ? bscale[b] : 1.f;       // per-sample factor (DropPath's mask / keep_prob of a residual branch)
         const size_t off = ((size_t)b * N + n) * P + p0 + 4 * q;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] *= gelu_grad_f(z[t]);
             }
+            if (bscale) o *= sc;
             if (addend) o += *reinterpret_cast<const floatx4*>(addend + off + 16 * i);
             *reinterpret_cast<floatx4*>(y + off + 16 * i) = o;
         }
@@ -307,16 +310,17 @@ inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
 
 template <int NT>
 int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, const float* addend,
-                float* y, int B, int K, int N, int P, int act_in, hipStream_t st, int G, long w_sg) {
+                float* y, int B, int K, int N, int P, int act_in, hipStream_t st, int G, long w_sg, const float* bscale) {
     const size_t lds = (size_t)K * lds_stride(NT) * sizeof(float);
     KMU_MAX_LDS((pw_gemm_kernel<NT>), lds);
     hipLaunchKernelGGL((pw_gemm_kernel<NT>), dim3(B * ((P + 255) / 256), N / (16 * NT)), dim3(256), lds, st, x, w, w_sn, w_sk, bias,
-                       mul_pre, addend, y, K, N, P, act_in, G, w_sg);
+                       mul_pre, addend, y, K, N, P, act_in, G, w_sg, bscale);
     return 0;
 }
 
 int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y,
-         int B, int K, int N, int P, int act_in, hipStream_t st, const float* addend = nullptr, int G = 1, long w_sg = 0) {
+         int B, int K, int N, int P, int act_in, hipStream_t st, const float* addend = nullptr, int G = 1, long w_sg = 0,
+         const float* bscale = nullptr) {
     // K = contraction channels PER GROUP, N = output channels in total (G groups of N / G)
     KMU_REQUIRE(B > 0 && K > 0 && N > 0 && K % 16 == 0 && N % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16",
                 what, K, N);
@@ -330,10 +334,10 @@ int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk,
     const long blocks_x = (long)B * ((P + 255) / 256);
     while (nt > 1 && blocks_x * (N / (16 * nt)) < 192) nt = (nt == 4) ? 2 : 1;
     switch (nt) {
-        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
-        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
-        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
-        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg); break;
+        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
+        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
+        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
+        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
     }
     return kmu::launch_status(what);
 }
@@ -376,6 +380,21 @@ extern "C" int kmu_pwconv_bwd_input_add(const float* gy, const float* w, const f
                                         kmu_stream_t stream) {
     KMU_REQUIRE(gy && w && addend && dx, "pwconv_bwd_input_add: null pointer");
     return gemm("pwconv_bwd_input_add", gy, w, 1, Ci, nullptr, nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream, addend);
+}
+
+// Residual forms for EnhancedViMBlock's tail, out = x + s[b] * ffn(...) (KM_UNetV3_SH.py:147-150; s = DropPath's per-sample factor or
+// NULL): forward y = addend + s[b] (W act(x) + bias); input gradient dx = s[b] (W^T gy) act'(x_pre).
+extern "C" int kmu_pwconv_fwd_res(const float* x, const float* w, const float* bias, const float* addend, const float* bscale, float* y,
+                                  int B, int Ci, int Co, int P, int act_in, kmu_stream_t stream) {
+    KMU_REQUIRE(x && w && addend && y, "pwconv_fwd_res: null pointer");
+    return gemm("pwconv_fwd_res", x, w, Ci, 1, bias, nullptr, y, B, Ci, Co, P, act_in, (hipStream_t)stream, addend, 1, 0, bscale);
+}
+extern "C" int kmu_pwconv_bwd_input_s(const float* gy, const float* w, const float* x_pre, const float* bscale, float* dx, int B, int Ci,
+                                      int Co, int P, int act_in, kmu_stream_t stream) {
+    KMU_REQUIRE(gy && w && dx, "pwconv_bwd_input_s: null pointer");
+    KMU_REQUIRE(!act_in || x_pre, "pwconv_bwd_input_s: act_in needs the pre-activation input");
+    return gemm("pwconv_bwd_input_s", gy, w, 1, Ci, nullptr, act_in ? x_pre : nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream, nullptr, 1, 0,
+                bscale);
 }
 
 extern "C" size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P) {

@@ -262,6 +262,11 @@ class EnhancedViMBlock(nn.Module):
         return self._ffn(x, dp)
 
     def _ffn(self, x, dp):
+        c, hw = x.shape[1], x.shape[2] * x.shape[3]
+        if x.is_cuda and not _TORCH_GLUE and ops.triple_norm_supported(c, hw) and ops.pwconv_supported(c, self.ffn[0].out_channels, hw) \
+                and self.ffn[0].bias is not None and self.ffn[2].bias is not None:
+            # TripleNorm -> 1x1 -> GELU -> 1x1 -> DropPath -> residual as one autograd node (ops.VimTailFn)
+            return ops.vim_tail(x, self.norm, self.ffn[0], self.ffn[2], dp.scale(x) if dp is not None else None)
         f = conv1x1(conv1x1(self.norm(x), self.ffn[0]), self.ffn[2], gelu_in=True)   # GELU folded into ffn[2]'s load
         s = dp.scale(x) if dp is not None else None
         return x + f if s is None else torch.addcmul(x, f, s.view(-1, 1, 1, 1))

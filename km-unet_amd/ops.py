@@ -866,6 +866,130 @@ def gated_mix3(x, f0, f1, f2, lin1, lin2, s=None):
     return GatedMix3Fn.apply(x, f0, f1, f2, lin1.weight, lin1.bias, lin2.weight, lin2.bias, s)
 
 
+# ------------------------------------------------------------------------------------------ EnhancedViMBlock tail
+def _k_tn_fwd(lib, x, gh, bh, gw, bw, gc, bc, eps_gn, eps_ln):
+    B, C = x.shape[:2]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    stats = torch.empty(B, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * C * lib.kmu_triple_norm_splits(HW) * 2, device=x.device, dtype=torch.float32)
+    _lib.check(_call(("triple_norm_fwd", (B, C, HW)), lib.kmu_triple_norm_fwd, _ptr(x), _ptr(gh), _ptr(bh), _ptr(gw), _ptr(bw), _ptr(gc),
+                     _ptr(bc), _ptr(y), _ptr(stats), _ptr(ws), B, C, HW, float(eps_gn), float(eps_ln), _stream()), "kmu_triple_norm_fwd")
+    return y, stats
+
+
+def _k_tn_bwd(lib, x, dy, gh, gw, gc, stats, addend, eps_ln):
+    B, C = x.shape[:2]
+    HW = x.numel() // (B * C)
+    dev = x.device
+    dx = torch.empty_like(x)
+    dgp, dbp = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
+    dcp = torch.empty(lib.kmu_triple_norm_partials(B, C, HW), C, device=dev, dtype=torch.float32)
+    ws = torch.empty(B * C * lib.kmu_triple_norm_splits(HW) * 2, device=dev, dtype=torch.float32)
+    _lib.check(_call(("triple_norm_bwd", (B, C, HW)), lib.kmu_triple_norm_bwd, _ptr(x), _ptr(dy), _ptr(gh), _ptr(gw), _ptr(gc), _ptr(stats),
+                     _ptr(addend), _ptr(dx), _ptr(dgp), _ptr(dbp), _ptr(dcp), _ptr(ws), B, C, HW, float(eps_ln), _stream()),
+               "kmu_triple_norm_bwd")
+    return dx, dgp, dbp, dcp
+
+
+def triple_norm_supported(C, HW):
+    return bool(_lib.load().kmu_triple_norm_supported(C, HW))
+
+
+class TripleNormFn(torch.autograd.Function):
+    """(GroupNorm_h(x) + GroupNorm_w(x) + LayerNorm_c(x)) / 3 (KM_UNetV3_SH.py:266-284) as one node: 2 launches each way."""
+
+    @staticmethod
+    def forward(ctx, x, gh, bh, gw, bw, gc, bc, eps_gn, eps_ln):
+        lib = _lib.load()
+        ctx.defer_wgrad = _leaf(gh, bh, gw, bw, gc, bc)
+        x = _f32c(x, "x")
+        p = [_f32c(t, "norm parameter") for t in (gh, bh, gw, bw, gc, bc)]
+        y, stats = _k_tn_fwd(lib, x, *p, eps_gn, eps_ln)
+        ctx.save_for_backward(x, p[0], p[2], p[4], stats)
+        ctx.eps_ln = float(eps_ln)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gh, gw, gc, stats = ctx.saved_tensors
+        dx, dgp, dbp, dcp = _k_tn_bwd(lib, x, _f32c(dy, "dy"), gh, gw, gc, stats, None, ctx.eps_ln)
+        C = x.shape[1]
+        dG, dB, dC = (torch.empty(C, device=x.device, dtype=torch.float32) for _ in range(3))
+        _wgrad(lambda: colsum(dgp, dbp, dcp, outs=[dG, dB, dC]), ctx.defer_wgrad)
+        return dx, dG, dB, dG, dB, dC, dB, None, None
+
+
+class VimTailFn(torch.autograd.Function):
+    """EnhancedViMBlock's tail as ONE autograd node (KM_UNetV3_SH.py:147-150):
+        out = x + s[b] * ffn2(GELU(ffn0(TripleNorm(x))))        s = DropPath's per-sample factor or None
+    forward 4 launches (TripleNorm sums + apply, two 1x1 convs with GELU-on-load, bias, residual and s folded in), backward 4 on
+    the dependent chain (two input gradients with GELU' / s folded in, TripleNorm sums + apply with the residual gradient as addend);
+    the separate nodes took 11 and ~22 -- on the main stream, where nothing else runs meanwhile."""
+
+    @staticmethod
+    def forward(ctx, x, gh, bh, gw, bw, gc, bc, eps_gn, eps_ln, w0, b0, w2, b2, s):
+        lib = _lib.load()
+        ctx.defer_wgrad = _leaf(gh, bh, gw, bw, gc, bc, w0, b0, w2, b2)
+        x = _f32c(x, "x")
+        p = [_f32c(t, "norm parameter") for t in (gh, bh, gw, bw, gc, bc)]
+        B, C, H, W = x.shape
+        P, hid = H * W, w0.shape[0]
+        w0c, w2c = _f32c(w0, "ffn[0].weight").view(hid, C), _f32c(w2, "ffn[2].weight").view(C, hid)
+        b0c, b2c = _f32c(b0, "ffn[0].bias"), _f32c(b2, "ffn[2].bias")
+        sc = None if s is None else _f32c(s, "s").view(B)
+        st = _stream()
+        n, stats = _k_tn_fwd(lib, x, *p, eps_gn, eps_ln)
+        h = torch.empty(B, hid, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("pwconv_fwd", (B, C, hid, P)), lib.kmu_pwconv_fwd, _ptr(n), _ptr(w0c), _ptr(b0c), _ptr(h), B, C, hid, P, 0, st),
+                   "kmu_pwconv_fwd")
+        out = torch.empty_like(x)
+        _lib.check(_call(("pwconv_fwd_res", (B, hid, C, P)), lib.kmu_pwconv_fwd_res, _ptr(h), _ptr(w2c), _ptr(b2c), _ptr(x), _ptr(sc),
+                         _ptr(out), B, hid, C, P, 1, st), "kmu_pwconv_fwd_res")
+        ctx.save_for_backward(x, p[0], p[2], p[4], stats, n, h, w0c, w2c, sc)
+        ctx.cfg = (float(eps_ln), tuple(w0.shape), tuple(w2.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, gh, gw, gc, stats, n, h, w0c, w2c, sc = ctx.saved_tensors
+        eps_ln, s0, s2 = ctx.cfg
+        g = _f32c(g, "grad")
+        B, C, H, W = x.shape
+        P, hid, dev, st = H * W, w0c.shape[0], x.device, _stream()
+        dh = torch.empty_like(h)                    # d loss / d ffn0 output = s (W2^T g) GELU'(h)
+        _lib.check(_call(("pwconv_bwd_input_s", (B, hid, C, P)), lib.kmu_pwconv_bwd_input_s, _ptr(g), _ptr(w2c), _ptr(h), _ptr(sc), _ptr(dh),
+                         B, hid, C, P, 1, st), "kmu_pwconv_bwd_input_s")
+        dn = torch.empty_like(n)
+        _lib.check(_call(("pwconv_bwd_input", (B, C, hid, P)), lib.kmu_pwconv_bwd_input, _ptr(dh), _ptr(w0c), None, _ptr(dn), B, C, hid, P, 0,
+                         st), "kmu_pwconv_bwd_input")
+        dx, dgp, dbp, dcp = _k_tn_bwd(lib, x, dn, gh, gw, gc, stats, g, eps_ln)
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        dw0, db0, dw2, db2, dG, dB, dC = mk(hid, C), mk(hid), mk(C, hid), mk(C), mk(C), mk(C), mk(C)
+
+        def job():
+            sg = g if sc is None else g * sc.view(B, 1, 1, 1)
+            nb2 = lib.kmu_pwconv_bwd_weight_ws_bytes(B, hid, C, P)
+            ws2 = torch.empty(nb2 // 4, device=dev, dtype=torch.float32)
+            _lib.check(_call(("pwconv_bwd_weight", (B, hid, C, P)), lib.kmu_pwconv_bwd_weight, _ptr(h), _ptr(sg), _ptr(dw2), _ptr(db2),
+                             _ptr(ws2), nb2, B, hid, C, P, 1, _stream()), "kmu_pwconv_bwd_weight")
+            nb0 = lib.kmu_pwconv_bwd_weight_ws_bytes(B, C, hid, P)
+            ws0 = torch.empty(nb0 // 4, device=dev, dtype=torch.float32)
+            _lib.check(_call(("pwconv_bwd_weight", (B, C, hid, P)), lib.kmu_pwconv_bwd_weight, _ptr(n), _ptr(dh), _ptr(dw0), _ptr(db0),
+                             _ptr(ws0), nb0, B, C, hid, P, 0, _stream()), "kmu_pwconv_bwd_weight")
+            colsum(dgp, dbp, dcp, outs=[dG, dB, dC])
+        _wgrad(job, ctx.defer_wgrad)
+        return dx, dG, dB, dG, dB, dC, dB, None, None, dw0.view(s0), db0, dw2.view(s2), db2, None
+
+
+def vim_tail(x, norm, ffn0, ffn2, s=None):
+    nh, nw, nc = norm.norm_h, norm.norm_w, norm.norm_c
+    return VimTailFn.apply(x, nh.weight, nh.bias, nw.weight, nw.bias, nc.weight, nc.bias, nh.eps, nc.eps, ffn0.weight, ffn0.bias,
+                           ffn2.weight, ffn2.bias, s)
+
+
 # ------------------------------------------------------------------------------------------ SSIM window filter
 class Gauss11Fn(torch.autograd.Function):
     """'valid' separable 11-tap filter over the last two dims (HybridLoss's SSIM window); backward = its adjoint."""

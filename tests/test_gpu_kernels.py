@@ -669,6 +669,43 @@ def test_gated_mix3_vs_torch_cpu(B, C, H, W, drop):
             dw2=rel_err(l2.weight.grad, w2.grad), db2=rel_err(l2.bias.grad, b2.grad))
 
 
+@pytest.mark.parametrize("B,C,H,W,drop", [(2, 16, 32, 32, True), (3, 32, 16, 16, False), (2, 64, 16, 16, True), (8, 16, 128, 128, True)])
+def test_vim_tail_vs_torch_cpu(B, C, H, W, drop):
+    """EnhancedViMBlock's tail (KM_UNetV3_SH.py:147-150, TripleNorm :266-284) as one node against torch fp64 on the CPU:
+    out = x + s * ffn2(GELU(ffn0((GN_h(x) + GN_w(x) + LN_c(x)) / 3))), GN over the H/W-transposed tensor for the 'height' norm."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + H)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
+    x = (torch.randn(B, C, H, W, generator=gen, dtype=torch.float64) * 1.5 + 0.3).requires_grad_(True)
+    gh, bh, gw, bw, gc, bc = mk(C), mk(C), mk(C), mk(C), mk(C), mk(C)
+    w0, b0, w2, b2 = mk(4 * C, C, 1, 1), mk(4 * C), mk(C, 4 * C, 1, 1), mk(C)
+    with torch.no_grad():
+        w0.mul_(0.3); w2.mul_(0.2)
+    s = (torch.rand(B, generator=gen, dtype=torch.float64) > 0.3).double() / 0.7 if drop else None
+    gy = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64)
+    nh = F.group_norm(x.transpose(2, 3), 1, gh, bh, 1e-5).transpose(2, 3)
+    nw = F.group_norm(x, 1, gw, bw, 1e-5)
+    nc = F.layer_norm(x.permute(0, 2, 3, 1), (C,), gc, bc, 1e-5).permute(0, 3, 1, 2)
+    f = F.conv2d(F.gelu(F.conv2d((nh + nw + nc) / 3, w0, b0)), w2, b2)
+    yo = x + (f if s is None else f * s.view(B, 1, 1, 1))
+    yo.backward(gy)
+    dev = lambda t: t.detach().float().to(DEV).requires_grad_(True)
+    xd = dev(x)
+    P = [dev(t) for t in (gh, bh, gw, bw, gc, bc, w0, b0, w2, b2)]
+    y = ops.VimTailFn.apply(xd, *P[:6], 1e-5, 1e-5, *P[6:], None if s is None else s.float().to(DEV))
+    y.backward(gy.float().to(DEV))
+    names = ("gh", "bh", "gw", "bw", "gc", "bc", "w0", "b0", "w2", "b2")
+    refs = (gh, bh, gw, bw, gc, bc, w0, b0, w2, b2)
+    _report("vim_tail %s" % ((B, C, H, W, drop),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad),
+            **{"d" + n: rel_err(t.grad, r.grad) for n, t, r in zip(names, P, refs)})
+    # the stand-alone TripleNorm node shares the kernels
+    xd2 = dev(x)
+    n = ops.TripleNormFn.apply(xd2, *[t.detach().requires_grad_(True) for t in P[:6]], 1e-5, 1e-5)
+    assert rel_err(n, ((nh + nw + nc) / 3).detach()) < TOL
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 16, 32, 32), (3, 64, 7, 9), (8, 32, 64, 64)])
 def test_spatial_mean_vs_torch_cpu(B, C, H, W):
     """AdaptiveAvgPool2d(1) of the squeeze-excite gates; the backward is an expanded view that must add up with a second
