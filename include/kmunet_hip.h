@@ -448,6 +448,13 @@ int kmu_contingency_counts(const float* pred, const float* target, unsigned long
                            const int* thresholds, int n_thresholds, float scale, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * DAGEM's edge features (DAGEM_md.py:56-62): edge[b,c,h,w,k] = x[b,c,h,w] * x[b,c,nbr_k(h,w)], nbr = (h-1,w), (h+1,w), (h,w-1), (h,w+1)
+ * cyclic (= torch.roll by +1 / -1 along H / W, stacked, times x); edge [B,C,H,W,4].  bwd: dx from d_edge (gather form, no atomics).
+ * ------------------------------------------------------------------------------------ */
+int kmu_dagem_edges_fwd(const float* x, float* edge, int B, int C, int H, int W, kmu_stream_t stream);
+int kmu_dagem_edges_bwd(const float* x, const float* d_edge, float* dx, int B, int C, int H, int W, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * TripleNorm (KM_UNetV3_SH.py:266-284): y = (GroupNorm_h(x) + GroupNorm_w(x) + LayerNorm_c(x)) / 3 on x [B,C,HW], C in {16,32,64}.
  * norm_h / norm_w = nn.GroupNorm(1, C) share their statistics (one group: invariant under the H/W transpose of the 'height' branch);
  * norm_c = nn.LayerNorm(C) on the channels-last view = per-pixel statistics over C.

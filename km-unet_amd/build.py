@@ -38,6 +38,7 @@ SOURCES = [
     ("conv3x3_x3.hip", []),
     ("resize.hip", []),
     ("triple_norm.hip", []),
+    ("dagem.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

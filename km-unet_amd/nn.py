@@ -351,6 +351,31 @@ class _SkinnyLinearFn(torch.autograd.Function):
         return dy @ w, (x * dy).sum(0, keepdim=True), dy.sum(0)
 
 
+def _bn_relu_rows(bn, yt):
+    """ReLU(BatchNorm1d(y)) for y given CHANNEL-MAJOR as yt [o, N] (row n of the reference's [N, o] activations = column n):
+    per-feature statistics over N are the NCHW BatchNorm kernel with B = 1, C = o, HW = N (csrc/bn_blend.hip: statistics +
+    apply-with-ReLU, 2 launches each way instead of ATen's batch_norm + relu chains).  Returns [o, N]."""
+    o = yt.shape[0]
+    tap, ops.RELU_TAP = ops.RELU_TAP, None          # the parity tooling wants the mask in the reference's [N, o] layout
+    try:
+        out = ops.bn_blend(yt.reshape(1, o, -1), None, bn, None, relu=True).view(o, -1)
+    finally:
+        ops.RELU_TAP = tap
+    if tap is not None:
+        tap.append((out.detach().t() > 0).cpu())
+    return out
+
+
+def _mlp_rows(seq, x):
+    """nn.Sequential(Linear(k, o), BatchNorm1d(o), ReLU) on rows x [N, k] (DAGEM_md.py:14-38), result CHANNEL-MAJOR [o, N]."""
+    lin, bn = seq[0], seq[1]
+    if lin.out_features == 1:
+        yt = _SkinnyLinearFn.apply(x, lin.weight, lin.bias).view(1, -1)
+    else:
+        yt = torch.addmm(lin.bias.unsqueeze(1), lin.weight, x.t())       # W x^T + b: [o, N] without a transpose pass
+    return _bn_relu_rows(bn, yt)
+
+
 def _mlp(seq, x):
     lin = seq[0]
     y = _SkinnyLinearFn.apply(x, lin.weight, lin.bias) if (lin.out_features == 1 and x.is_cuda) else lin(x)
@@ -375,14 +400,25 @@ class DAGEM(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
-        nb = torch.stack((x.roll(1, 2), x.roll(-1, 2), x.roll(1, 3), x.roll(-1, 3)), dim=-1)
-        edge = nb * x.unsqueeze(-1)                                                   # [B,C,H,W,4]
-        agg = _mlp(self.edge_aggregation_func, edge.reshape(-1, 4)).view(b, c, h, w)
-        vert = self.vertex_update_func(torch.cat((x, agg), 1).permute(0, 2, 3, 1).reshape(-1, 2 * c))
-        vert = vert.view(b, h, w, c // 2).permute(0, 3, 1, 2)
-        ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1).permute(0, 2, 3, 4, 1).reshape(-1, 2 * c)
-        ue = self.edge_update_func(ef).view(b, h, w, 4, c // 2).permute(0, 4, 1, 2, 3).reshape(-1, 4)
-        ue = _mlp(self.update_edge_reduce_func, ue).view(b, c // 2, h, w)
+        if x.is_cuda and "dagem" not in _TORCH_GLUE:
+            # same arithmetic, fewer launches: edge products by one gather kernel, Linear outputs kept channel-major so that
+            # BatchNorm1d + ReLU run on the NCHW BatchNorm kernels
+            edge = ops.dagem_edges(x)                                                     # [B,C,H,W,4]
+            agg = _mlp_rows(self.edge_aggregation_func, edge.reshape(-1, 4)).view(b, c, h, w)
+            vert = _mlp_rows(self.vertex_update_func, torch.cat((x, agg), 1).permute(0, 2, 3, 1).reshape(-1, 2 * c))
+            vert = vert.view(c // 2, b, h, w).permute(1, 0, 2, 3)                          # [c/2, (b,h,w)] -> [B,c/2,H,W] (view)
+            ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1).permute(0, 2, 3, 4, 1).reshape(-1, 2 * c)
+            ue = _mlp_rows(self.edge_update_func, ef).view(c // 2, b, h, w, 4).permute(1, 0, 2, 3, 4).reshape(-1, 4)
+            ue = _mlp_rows(self.update_edge_reduce_func, ue).view(b, c // 2, h, w)
+        else:
+            nb = torch.stack((x.roll(1, 2), x.roll(-1, 2), x.roll(1, 3), x.roll(-1, 3)), dim=-1)
+            edge = nb * x.unsqueeze(-1)                                                   # [B,C,H,W,4]
+            agg = _mlp(self.edge_aggregation_func, edge.reshape(-1, 4)).view(b, c, h, w)
+            vert = self.vertex_update_func(torch.cat((x, agg), 1).permute(0, 2, 3, 1).reshape(-1, 2 * c))
+            vert = vert.view(b, h, w, c // 2).permute(0, 3, 1, 2)
+            ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1).permute(0, 2, 3, 4, 1).reshape(-1, 2 * c)
+            ue = self.edge_update_func(ef).view(b, h, w, 4, c // 2).permute(0, 4, 1, 2, 3).reshape(-1, 4)
+            ue = _mlp(self.update_edge_reduce_func, ue).view(b, c // 2, h, w)
         deformed = self.deform_conv(x, conv3x3(x, self.offset_conv)) + x
         fa = self.final_aggregation_layer
         return fa[2](fa[1](conv1x1(torch.cat((deformed, vert * ue), 1), fa[0])))

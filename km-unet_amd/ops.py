@@ -866,6 +866,37 @@ def gated_mix3(x, f0, f1, f2, lin1, lin2, s=None):
     return GatedMix3Fn.apply(x, f0, f1, f2, lin1.weight, lin1.bias, lin2.weight, lin2.bias, s)
 
 
+# ------------------------------------------------------------------------------------------ DAGEM edge features
+class DagemEdgesFn(torch.autograd.Function):
+    """edge[b,c,h,w,k] = x * roll_k(x), k = roll(+1, H), roll(-1, H), roll(+1, W), roll(-1, W)  (DAGEM_md.py:56-62)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, C, H, W = x.shape
+        edge = torch.empty(B, C, H, W, 4, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("dagem_edges_fwd", (B, C, H, W)), lib.kmu_dagem_edges_fwd, _ptr(x), _ptr(edge), B, C, H, W, _stream()),
+                   "kmu_dagem_edges_fwd")
+        ctx.save_for_backward(x)
+        return edge
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(_call(("dagem_edges_bwd", (B, C, H, W)), lib.kmu_dagem_edges_bwd, _ptr(x), _ptr(g), _ptr(dx), B, C, H, W, _stream()),
+                   "kmu_dagem_edges_bwd")
+        return dx
+
+
+def dagem_edges(x):
+    return DagemEdgesFn.apply(x)
+
+
 # ------------------------------------------------------------------------------------------ EnhancedViMBlock tail
 def _k_tn_fwd(lib, x, gh, bh, gw, bw, gc, bc, eps_gn, eps_ln):
     B, C = x.shape[:2]

@@ -706,6 +706,21 @@ def test_vim_tail_vs_torch_cpu(B, C, H, W, drop):
     assert rel_err(n, ((nh + nw + nc) / 3).detach()) < TOL
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 16, 16), (1, 3, 5, 7), (8, 64, 16, 16)])
+def test_dagem_edges_vs_torch_cpu(B, C, H, W):
+    """DAGEM_md.py:56-62: four cyclic neighbour products, forward and the gather-form adjoint, against torch.roll in fp64."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
+    gy = torch.randn(B, C, H, W, 4, generator=gen, dtype=torch.float64)
+    eo = torch.stack((x.roll(1, 2), x.roll(-1, 2), x.roll(1, 3), x.roll(-1, 3)), dim=-1) * x.unsqueeze(-1)
+    eo.backward(gy)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    e = ops.dagem_edges(xd)
+    e.backward(gy.float().to(DEV))
+    _report("dagem_edges %s" % ((B, C, H, W),), edge=rel_err(e, eo), dx=rel_err(xd.grad, x.grad))
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 16, 32, 32), (3, 64, 7, 9), (8, 32, 64, 64)])
 def test_spatial_mean_vs_torch_cpu(B, C, H, W):
     """AdaptiveAvgPool2d(1) of the squeeze-excite gates; the backward is an expanded view that must add up with a second
