@@ -421,7 +421,10 @@ class DAGEM(nn.Module):
             ue = _mlp(self.update_edge_reduce_func, ue).view(b, c // 2, h, w)
         deformed = self.deform_conv(x, conv3x3(x, self.offset_conv)) + x
         fa = self.final_aggregation_layer
-        return fa[2](fa[1](conv1x1(torch.cat((deformed, vert * ue), 1), fa[0])))
+        z = conv1x1(torch.cat((deformed, vert * ue), 1), fa[0])
+        if x.is_cuda and "dagem" not in _TORCH_GLUE and "bn_blend" not in _TORCH_GLUE:
+            return ops.bn_blend(z, None, fa[1], None, relu=True)        # BatchNorm2d + ReLU: statistics + apply, 2 launches each way
+        return fa[2](fa[1](z))
 
 
 # ------------------------------------------------------------------ WPL/iwp.py (glue)
