@@ -376,6 +376,23 @@ def _mlp_rows(seq, x):
     return _bn_relu_rows(bn, yt)
 
 
+def _conv_bn_relu(seq, t):
+    """The same Sequential(Linear(k, o), BatchNorm1d(o), ReLU) applied to the channel axis of t [B, k, ...]: a Linear over the
+    channels-last rows IS a 1x1 convolution, and BatchNorm1d over those rows is BatchNorm2d -- so the reference's
+    cat -> permute -> reshape -> Linear -> ... -> view -> permute round trips (DAGEM_md.py:66-69, :74-81) disappear: NCHW in, NCHW
+    out, on the pointwise-conv and BatchNorm kernels.  The ReLU mask is reported in the reference's [rows, o] layout."""
+    lin, bn = seq[0], seq[1]
+    y = ops.pwconv(t.reshape(t.shape[0], t.shape[1], -1, 1), lin.weight, lin.bias)
+    tap, ops.RELU_TAP = ops.RELU_TAP, None
+    try:
+        out = ops.bn_blend(y, None, bn, None, relu=True)
+    finally:
+        ops.RELU_TAP = tap
+    if tap is not None:
+        tap.append((out.detach().flatten(2).permute(0, 2, 1).reshape(-1, out.shape[1]) > 0).cpu())
+    return out
+
+
 def _mlp(seq, x):
     lin = seq[0]
     y = _SkinnyLinearFn.apply(x, lin.weight, lin.bias) if (lin.out_features == 1 and x.is_cuda) else lin(x)
@@ -405,11 +422,17 @@ class DAGEM(nn.Module):
             # BatchNorm1d + ReLU run on the NCHW BatchNorm kernels
             edge = ops.dagem_edges(x)                                                     # [B,C,H,W,4]
             agg = _mlp_rows(self.edge_aggregation_func, edge.reshape(-1, 4)).view(b, c, h, w)
-            vert = _mlp_rows(self.vertex_update_func, torch.cat((x, agg), 1).permute(0, 2, 3, 1).reshape(-1, 2 * c))
-            vert = vert.view(c // 2, b, h, w).permute(1, 0, 2, 3)                          # [c/2, (b,h,w)] -> [B,c/2,H,W] (view)
-            ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1).permute(0, 2, 3, 4, 1).reshape(-1, 2 * c)
-            ue = _mlp_rows(self.edge_update_func, ef).view(c // 2, b, h, w, 4).permute(1, 0, 2, 3, 4).reshape(-1, 4)
-            ue = _mlp_rows(self.update_edge_reduce_func, ue).view(b, c // 2, h, w)
+            ef = torch.cat((x.unsqueeze(-1).expand_as(edge), edge), 1)                    # [B,2C,H,W,4]
+            if ops.pwconv_supported(2 * c, c // 2, h * w):
+                vert = _conv_bn_relu(self.vertex_update_func, torch.cat((x, agg), 1)).view(b, c // 2, h, w)
+                ue = _conv_bn_relu(self.edge_update_func, ef)                             # [B,C/2,(H,W,4)]: rows of 4 already contiguous
+                ue = _mlp_rows(self.update_edge_reduce_func, ue.reshape(-1, 4)).view(b, c // 2, h, w)
+            else:
+                vert = _mlp_rows(self.vertex_update_func, torch.cat((x, agg), 1).permute(0, 2, 3, 1).reshape(-1, 2 * c))
+                vert = vert.view(c // 2, b, h, w).permute(1, 0, 2, 3)                      # [c/2, (b,h,w)] -> [B,c/2,H,W] (view)
+                ue = _mlp_rows(self.edge_update_func, ef.permute(0, 2, 3, 4, 1).reshape(-1, 2 * c))
+                ue = ue.view(c // 2, b, h, w, 4).permute(1, 0, 2, 3, 4).reshape(-1, 4)
+                ue = _mlp_rows(self.update_edge_reduce_func, ue).view(b, c // 2, h, w)
         else:
             nb = torch.stack((x.roll(1, 2), x.roll(-1, 2), x.roll(1, 3), x.roll(-1, 3)), dim=-1)
             edge = nb * x.unsqueeze(-1)                                                   # [B,C,H,W,4]
