@@ -448,6 +448,13 @@ int kmu_contingency_counts(const float* pred, const float* target, unsigned long
                            const int* thresholds, int n_thresholds, float scale, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * LocalContrastAttention's output (KM_UNetV3_SH.py:366-368): y = x (1 - g) + g, g [B,C] (= torch.lerp(x, ones, g[:,:,None,None]));
+ * bwd: dx = dy (1 - g), dg[b,c] = sum_hw dy (1 - x) in one pass.
+ * ------------------------------------------------------------------------------------ */
+int kmu_lca_fwd(const float* x, const float* g, float* y, int B, int C, int HW, kmu_stream_t stream);
+int kmu_lca_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int B, int C, int HW, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * DAGEM's edge features (DAGEM_md.py:56-62): edge[b,c,h,w,k] = x[b,c,h,w] * x[b,c,nbr_k(h,w)], nbr = (h-1,w), (h+1,w), (h,w-1), (h,w+1)
  * cyclic (= torch.roll by +1 / -1 along H / W, stacked, times x); edge [B,C,H,W,4].  bwd: dx from d_edge (gather form, no atomics).
  * ------------------------------------------------------------------------------------ */

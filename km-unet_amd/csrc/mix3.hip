@@ -116,6 +116,47 @@ __global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* __restrict__
             sc * ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
+// LocalContrastAttention's output (KM_UNetV3_SH.py:366-368): x * (1 - g) + g with g [B,C] the sigmoid gate of the pooled channel
+// groups (torch.lerp(x, 1, g)).  One workgroup per (b, c) plane; the backward writes dx = dy (1 - g) and reduces
+// dg[b,c] = sum_p dy (1 - x) in the same pass (deterministic).
+__global__ __launch_bounds__(256) void lca_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ y, int HW) {
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float gv = g[blockIdx.x], a = 1.f - gv;
+    if ((HW & 3) == 0) {
+        for (int i = threadIdx.x; i < HW / 4; i += 256) {
+            const floatx4 v = reinterpret_cast<const floatx4*>(x + base)[i];
+            reinterpret_cast<floatx4*>(y + base)[i] = v * a + gv;
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) y[base + i] = x[base + i] * a + gv;
+    }
+}
+
+__global__ __launch_bounds__(256) void lca_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, float* __restrict__ dg, int HW) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float a = 1.f - g[blockIdx.x];
+    float s = 0.f;
+    if ((HW & 3) == 0) {
+        for (int i = threadIdx.x; i < HW / 4; i += 256) {
+            const floatx4 v = reinterpret_cast<const floatx4*>(x + base)[i], d = reinterpret_cast<const floatx4*>(dy + base)[i];
+            reinterpret_cast<floatx4*>(dx + base)[i] = d * a;
+            s += (d[0] * (1.f - v[0]) + d[1] * (1.f - v[1])) + (d[2] * (1.f - v[2]) + d[3] * (1.f - v[3]));
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const float d = dy[base + i];
+            dx[base + i] = d * a;
+            s += d * (1.f - x[base + i]);
+        }
+    }
+    s = kmu::wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dg[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
 
 extern "C" int kmu_mix3_blocks(int n_per_sample) { return n_per_sample > 0 ? kmu::cdiv(n_per_sample / 4, 256 * VPT) : 0; }
@@ -205,4 +246,19 @@ extern "C" int kmu_mix3_bwd_apply_stacked(const float* dy, const float* g, const
     hipLaunchKernelGGL(mix3_bwd_apply_kernel, dim3(kmu_mix3_blocks(n), B), dim3(256), 0, (hipStream_t)stream, dy, g, s, d_pooled, dF, dF + n,
                        dF + 2 * (size_t)n, n / 4, C, HW / 4, 1.0f / (float)HW, 3 * (n / 4));
     return kmu::launch_status("mix3_bwd_apply_stacked");
+}
+
+extern "C" int kmu_lca_fwd(const float* x, const float* g, float* y, int B, int C, int HW, kmu_stream_t stream) {
+    KMU_REQUIRE(x && g && y, "lca_fwd: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && HW > 0, "lca_fwd: bad dims");
+    hipLaunchKernelGGL(lca_fwd_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, x, g, y, HW);
+    return kmu::launch_status("lca_fwd");
+}
+
+extern "C" int kmu_lca_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int B, int C, int HW,
+                           kmu_stream_t stream) {
+    KMU_REQUIRE(x && g && dy && dx && dg, "lca_bwd: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && HW > 0, "lca_bwd: bad dims");
+    hipLaunchKernelGGL(lca_bwd_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, x, g, dy, dx, dg, HW);
+    return kmu::launch_status("lca_bwd");
 }

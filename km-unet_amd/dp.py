@@ -56,6 +56,8 @@ class FlatGradBucket:
         # down the per-tensor path: +2.5 ms per step); stragglers are copied on their own
         fast_v, fast_g = [], []
         for v, g in zip(self.views, grads):
+            if g.stride() != v.stride() and g.is_contiguous():
+                g = g.view(-1).view(v.shape)        # same memory, canonical strides (size-1 dims may carry any stride): fast path
             if g.stride() == v.stride() and g.dtype == v.dtype:
                 fast_v.append(v)
                 fast_g.append(g)

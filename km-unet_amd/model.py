@@ -310,8 +310,10 @@ class LocalContrastAttention(nn.Module):
 
     def forward(self, x):
         avg = _spatial_mean(x)
-        g = gate_mlp(avg.view(avg.shape[0], -1, self.reduction_ratio).mean(-1), self.fc[0], self.fc[2], "relu")[:, :, None, None]
-        return torch.lerp(x, torch.ones_like(x), g)          # x*(1-g) + g
+        g = gate_mlp(avg.view(avg.shape[0], -1, self.reduction_ratio).mean(-1), self.fc[0], self.fc[2], "relu")
+        if x.is_cuda and not _TORCH_GLUE:
+            return ops.lca_apply(x, g)                       # x*(1-g) + g: one launch each way
+        return torch.lerp(x, torch.ones_like(x), g[:, :, None, None])
 
 
 class KM_UNetV3(nn.Module):

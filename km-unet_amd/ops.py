@@ -866,6 +866,40 @@ def gated_mix3(x, f0, f1, f2, lin1, lin2, s=None):
     return GatedMix3Fn.apply(x, f0, f1, f2, lin1.weight, lin1.bias, lin2.weight, lin2.bias, s)
 
 
+# ------------------------------------------------------------------------------------------ LocalContrastAttention output
+class LcaApplyFn(torch.autograd.Function):
+    """x * (1 - g) + g with g [B, C] (KM_UNetV3_SH.py:366-368, torch.lerp(x, 1, g)): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        lib = _lib.load()
+        x, g = _f32c(x, "x"), _f32c(g, "gate")
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        _lib.check(_call(("lca_fwd", (B, C, HW)), lib.kmu_lca_fwd, _ptr(x), _ptr(g), _ptr(y), B, C, HW, _stream()), "kmu_lca_fwd")
+        ctx.save_for_backward(x, g)
+        ctx.gshape = tuple(g.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, g = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        dg = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("lca_bwd", (B, C, HW)), lib.kmu_lca_bwd, _ptr(x), _ptr(g), _ptr(dy), _ptr(dx), _ptr(dg), B, C, HW, _stream()),
+                   "kmu_lca_bwd")
+        return dx, dg.view(ctx.gshape)
+
+
+def lca_apply(x, g):
+    return LcaApplyFn.apply(x, g)
+
+
 # ------------------------------------------------------------------------------------------ DAGEM edge features
 class DagemEdgesFn(torch.autograd.Function):
     """edge[b,c,h,w,k] = x * roll_k(x), k = roll(+1, H), roll(-1, H), roll(+1, W), roll(-1, W)  (DAGEM_md.py:56-62)."""

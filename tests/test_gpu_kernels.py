@@ -706,6 +706,22 @@ def test_vim_tail_vs_torch_cpu(B, C, H, W, drop):
     assert rel_err(n, ((nh + nw + nc) / 3).detach()) < TOL
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 32, 32), (3, 5, 7, 9), (8, 64, 16, 16)])
+def test_lca_apply_vs_torch_cpu(B, C, H, W):
+    """KM_UNetV3_SH.py:366-368: torch.lerp(x, ones, g) with a per-(b, c) gate, forward and both gradients."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(B * C)
+    x = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
+    g = torch.rand(B, C, generator=gen, dtype=torch.float64).requires_grad_(True)
+    gy = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64)
+    yo = torch.lerp(x, torch.ones_like(x), g[:, :, None, None])
+    yo.backward(gy)
+    xd, gd = x.detach().float().to(DEV).requires_grad_(True), g.detach().float().to(DEV).requires_grad_(True)
+    y = ops.lca_apply(xd, gd)
+    y.backward(gy.float().to(DEV))
+    _report("lca_apply %s" % ((B, C, H, W),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad), dg=rel_err(gd.grad, g.grad))
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 8, 16, 16), (1, 3, 5, 7), (8, 64, 16, 16)])
 def test_dagem_edges_vs_torch_cpu(B, C, H, W):
     """DAGEM_md.py:56-62: four cyclic neighbour products, forward and the gather-form adjoint, against torch.roll in fp64."""
