@@ -448,6 +448,16 @@ int kmu_contingency_counts(const float* pred, const float* target, unsigned long
                            const int* thresholds, int n_thresholds, float scale, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * kmu_pwconv_bwd_weight in two halves, for callers that collect many weight gradients (a train step's weight-gradient tail is
+ * bound by its launch count): the slab pass of one gradient into its workspace (kmu_pwconv_bwd_weight_ws_bytes), and the slab
+ * reduction of up to 32 of them in one launch.  kmu_colsum_multi likewise takes up to 64 arrays.
+ * ------------------------------------------------------------------------------------ */
+int kmu_pwconv_bwd_weight_partial(const float* x, const float* gy, void* ws, size_t ws_bytes, int with_bias, int B, int Ci, int Co, int P,
+                                  int act_in, kmu_stream_t stream);
+int kmu_pwconv_bwd_weight_reduce_multi(int n, const void* const* ws, float* const* dw, float* const* dbias, const int* B, const int* Ci,
+                                       const int* Co, const int* P, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * LocalContrastAttention's output (KM_UNetV3_SH.py:366-368): y = x (1 - g) + g, g [B,C] (= torch.lerp(x, ones, g[:,:,None,None]));
  * bwd: dx = dy (1 - g), dg[b,c] = sum_hw dy (1 - x) in one pass.
  * ------------------------------------------------------------------------------------ */

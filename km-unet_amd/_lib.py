@@ -123,6 +123,8 @@ SIGNATURES = {
     "kmu_mix3_fwd_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),
     "kmu_mix3_bwd_dg_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),
     "kmu_mix3_bwd_apply_stacked": (_I, [_P] * 5 + [_I] * 3 + [_P]),
+    "kmu_pwconv_bwd_weight_partial": (_I, [_P] * 3 + [_Z] + [_I] * 6 + [_P]),
+    "kmu_pwconv_bwd_weight_reduce_multi": (_I, [_I] + [_P] * 7 + [_P]),
     "kmu_lca_fwd": (_I, [_P] * 3 + [_I] * 3 + [_P]),
     "kmu_lca_bwd": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "kmu_dagem_edges_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),

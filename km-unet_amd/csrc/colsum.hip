@@ -1,12 +1,12 @@
 // Second stage of the deterministic two-stage reductions: every backward kernel of this library leaves its
-// parameter gradients as per-workgroup partial rows [rows][cols]; this kernel column-sums up to 8 such arrays in ONE
+// parameter gradients as per-workgroup partial rows [rows][cols]; this kernel column-sums up to 64 such arrays in ONE
 // launch (fixed summation order, no atomics).  Replaces one ATen reduce launch per array -- e.g. five per
 // HSMSSD backward (d_w_bcdt, d_w_dw, d_w_hz, d_w_out, d_D).
 #include "common.h"
 
 namespace {
 
-constexpr int MAXA = 8, COLS = 32, PARTS = 8;
+constexpr int MAXA = 64, COLS = 32, PARTS = 8;     // 64 arrays: 1.8 KB of kernel arguments
 
 struct ColsumArgs {
     const float* src[MAXA];

@@ -282,6 +282,61 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __res
     }
 }
 
+// the same reduction for up to 32 weight gradients in ONE launch (the weight-gradient tail of a train step is bound by its
+// launch COUNT: ~500 launches of ~5 us on three streams take 1.45 ms)
+constexpr int RMAX = 32;
+struct ReduceMultiArgs {
+    const float* slab[RMAX];
+    const float* bslab[RMAX];
+    float* dw[RMAX];
+    float* dbias[RMAX];
+    int Ci[RMAX], Co[RMAX], MT[RMAX], NT[RMAX], G[RMAX], wblocks[RMAX], blk0[RMAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_multi_kernel(ReduceMultiArgs a) {
+    __shared__ floatx4 part[16][16];
+    int k = 0;
+    while (k + 1 < a.n && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
+    const int bid = blockIdx.x - a.blk0[k];
+    const float* __restrict__ slab = a.slab[k];
+    const float* __restrict__ bslab = a.bslab[k];
+    float* __restrict__ dw = a.dw[k];
+    float* __restrict__ dbias = a.dbias[k];
+    const int Ci = a.Ci[k], MT = a.MT[k], NT = a.NT[k], G = a.G[k], wblocks = a.wblocks[k];
+    const int o = threadIdx.x & 15, pt = threadIdx.x >> 4;
+    const int per_sp = MT * NT * 64, nsl_i = Ci / (16 * NT);
+    if (bid < wblocks) {
+        const int t = bid * 16 + o;
+        const int sp = t / per_sp, e = t - sp * per_sp, tile = e >> 6, lane = e & 63;
+        const float* src = slab + ((size_t)sp * G * MT * NT + tile) * 256 + lane * 4;
+        floatx4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int g = pt; g < G; g += 16) s += *reinterpret_cast<const floatx4*>(src + (size_t)g * MT * NT * 256);
+        part[pt][o] = s;
+        __syncthreads();
+        if (pt == 0) {
+#pragma unroll
+            for (int j = 1; j < 16; ++j) s += part[j][o];
+            const int mt = tile / NT, nt = tile - mt * NT, r = lane & 15, q = lane >> 4;
+            const int co = (sp / nsl_i) * 16 * MT + 16 * mt + 4 * q, ci = (sp % nsl_i) * 16 * NT + 16 * nt + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw[(size_t)(co + i) * Ci + ci] = s[i];
+        }
+    } else {
+        const int t = (bid - wblocks) * 16 + o;
+        const int so = t / (16 * MT), rem = t - so * 16 * MT;
+        const float* src = bslab + (size_t)so * G * MT * 16 + rem;
+        float s = 0.f;
+        for (int g = pt; g < G; g += 16) s += src[(size_t)g * MT * 16];
+        part[pt][o][0] = s;
+        __syncthreads();
+        if (pt == 0) {
+#pragma unroll
+            for (int j = 1; j < 16; ++j) s += part[j][o][0];
+            dbias[t] = s;
+        }
+    }
+}
+
 inline int pick_tiles(int n16) { return n16 % 4 == 0 ? 4 : (n16 % 3 == 0 ? 3 : (n16 % 2 == 0 ? 2 : 1)); }
 
 struct WgradPlan {
@@ -404,8 +459,8 @@ extern "C" size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P) {
 }
 
 static int pw_bwd_weight(const char* what, const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B,
-                        int Ci, int Co, int P, int act_in, hipStream_t st, int XC, int GC) {
-    KMU_REQUIRE(x && gy && dw && ws, "%s: null pointer", what);
+                        int Ci, int Co, int P, int act_in, hipStream_t st, int XC, int GC, bool reduce = true) {
+    KMU_REQUIRE(x && gy && (dw || !reduce) && ws, "%s: null pointer", what);
     KMU_REQUIRE(B > 0 && Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16", what,
                 Ci, Co);
     KMU_REQUIRE(P > 0 && P % 32 == 0, "%s: H*W = %d must be a positive multiple of 32", what, P);
@@ -421,11 +476,43 @@ static int pw_bwd_weight(const char* what, const float* x, const float* gy, floa
         default: launch_wgrad_nt<1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
     }
     int rc = kmu::launch_status(what);
-    if (rc) return rc;
+    if (rc || !reduce) return rc;
     const int wblocks = pl.nsp * pl.MT * pl.NT * 64 / 16, bblocks = dbias ? Co / 16 : 0;
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, slab, bslab, dw, dbias, Ci, Co, pl.MT, pl.NT,
                        pl.G, wblocks);
     return kmu::launch_status(what);
+}
+
+// The two halves of kmu_pwconv_bwd_weight separately: the slab pass of ONE weight gradient (with_bias: also the bias slabs), and the
+// slab reduction of up to 32 of them in one launch (ws[i] / dw[i] / dbias[i] / dims of problem i; dbias[i] NULL = no bias).
+extern "C" int kmu_pwconv_bwd_weight_partial(const float* x, const float* gy, void* ws, size_t ws_bytes, int with_bias, int B, int Ci,
+                                             int Co, int P, int act_in, kmu_stream_t stream) {
+    float dummy;
+    return pw_bwd_weight("pwconv_bwd_weight_partial", x, gy, nullptr, with_bias ? &dummy : nullptr, ws, ws_bytes, B, Ci, Co, P, act_in,
+                         (hipStream_t)stream, Ci, Co, false);
+}
+
+extern "C" int kmu_pwconv_bwd_weight_reduce_multi(int n, const void* const* ws, float* const* dw, float* const* dbias, const int* B,
+                                                  const int* Ci, const int* Co, const int* P, kmu_stream_t stream) {
+    KMU_REQUIRE(n > 0 && n <= RMAX && ws && dw && dbias && B && Ci && Co && P, "pwconv_bwd_weight_reduce_multi: %d problems (1..%d)", n, RMAX);
+    ReduceMultiArgs a;
+    a.n = n;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        KMU_REQUIRE(ws[k] && dw[k], "pwconv_bwd_weight_reduce_multi: problem %d has a null pointer", k);
+        const WgradPlan pl = wgrad_plan(B[k], Ci[k], Co[k], P[k]);
+        a.slab[k] = (const float*)ws[k];
+        a.bslab[k] = dbias[k] ? (const float*)ws[k] + pl.slab_floats : nullptr;
+        a.dw[k] = dw[k];
+        a.dbias[k] = dbias[k];
+        a.Ci[k] = Ci[k], a.Co[k] = Co[k], a.MT[k] = pl.MT, a.NT[k] = pl.NT, a.G[k] = pl.G;
+        a.wblocks[k] = pl.nsp * pl.MT * pl.NT * 64 / 16;
+        a.blk0[k] = blocks;
+        blocks += a.wblocks[k] + (dbias[k] ? Co[k] / 16 : 0);
+    }
+    a.blk0[n] = blocks;
+    hipLaunchKernelGGL(pw_wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return kmu::launch_status("pwconv_bwd_weight_reduce_multi");
 }
 
 extern "C" int kmu_pwconv_bwd_weight(const float* x, const float* gy, float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int Ci,
