@@ -448,6 +448,22 @@ int kmu_contingency_counts(const float* pred, const float* target, unsigned long
                            const int* thresholds, int n_thresholds, float scale, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Convolution + the statistics pass of the BatchNorm behind it (ConvLayer2D = conv + BatchNorm2d, vim_utils_init.py:62-89, in
+ * EfficientViMBlock's dwconv1 / dwconv2 / FFN): the conv kernel leaves per-workgroup (sum, sum of squares) of its output,
+ * stat_part [C][S][2] with S = kmu_*_stats_partials(...) (0 = shape not covered: use the plain entry points), and
+ * kmu_bn_blend_fwd_pre is train-mode kmu_bn_blend_fwd reading those partials -- one launch and one read of the tensor less.
+ * ------------------------------------------------------------------------------------ */
+int kmu_dwconv3x3_stats_partials(int B, int C, int H, int W);
+int kmu_dwconv3x3_fwd_stats(const float* x, const float* weight, const float* bias, float* y, float* stat_part, int B, int C, int H, int W,
+                            kmu_stream_t stream);
+int kmu_pwconv_stats_partials(int B, int P);
+int kmu_pwconv_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stat_part, int B, int Ci, int Co, int P,
+                         int act_in, kmu_stream_t stream);
+int kmu_bn_blend_fwd_pre(const float* t, const float* x, const float* gamma, const float* beta, const float* alpha, float* running_mean,
+                         float* running_var, float momentum, float eps, int relu, float* out, float* stats, const float* stat_part,
+                         int S_part, long long* num_batches_tracked, int B, int C, int HW, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * kmu_pwconv_bwd_weight in two halves, for callers that collect many weight gradients (a train step's weight-gradient tail is
  * bound by its launch count): the slab pass of one gradient into its workspace (kmu_pwconv_bwd_weight_ws_bytes), and the slab
  * reduction of up to 32 of them in one launch.  kmu_colsum_multi likewise takes up to 64 arrays.

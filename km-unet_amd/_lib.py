@@ -125,6 +125,11 @@ SIGNATURES = {
     "kmu_mix3_bwd_apply_stacked": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "kmu_pwconv_bwd_weight_partial": (_I, [_P] * 3 + [_Z] + [_I] * 6 + [_P]),
     "kmu_pwconv_bwd_weight_reduce_multi": (_I, [_I] + [_P] * 7 + [_P]),
+    "kmu_dwconv3x3_stats_partials": (_I, [_I] * 4),
+    "kmu_dwconv3x3_fwd_stats": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "kmu_pwconv_stats_partials": (_I, [_I] * 2),
+    "kmu_pwconv_fwd_stats": (_I, [_P] * 5 + [_I] * 5 + [_P]),
+    "kmu_bn_blend_fwd_pre": (_I, [_P] * 7 + [_c.c_float, _c.c_float, _I] + [_P] * 3 + [_I, _P] + [_I] * 3 + [_P]),
     "kmu_lca_fwd": (_I, [_P] * 3 + [_I] * 3 + [_P]),
     "kmu_lca_bwd": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "kmu_dagem_edges_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),

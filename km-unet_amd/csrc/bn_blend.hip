@@ -82,18 +82,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        float momentum, float eps, int relu, int training,
                                                        float* __restrict__ out, float* __restrict__ stats_out,
                                                        long long* __restrict__ num_batches_tracked, int B, int C, int HW,
-                                                       int chunk) {
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+                                                       int chunk, int SP) {
+    // SP: partial pairs per channel in `part` (= gridDim.y when bn_stats_kernel made them; the producing convolution's workgroups
+    // per channel when IT made them: kmu_bn_blend_fwd_pre)
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
     if (num_batches_tracked && training && gamma && c == 0 && s == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const long N = (long)B * HW;
     float mean = 0.f, rstd = 1.f, g = 1.f, bt = 0.f;
     if (gamma) {
         if (training) {
-            double sa = 0.0, sq = 0.0;
-            for (int i = 0; i < S; ++i) {
-                sa += part[((size_t)c * S + i) * 2];
-                sq += part[((size_t)c * S + i) * 2 + 1];
+            double da = 0.0, dq = 0.0;
+            for (int i = threadIdx.x; i < SP; i += 256) {
+                da += part[((size_t)c * SP + i) * 2];
+                dq += part[((size_t)c * SP + i) * 2 + 1];
             }
+            const double sa = (double)block_sum((float)da, red), sq = (double)block_sum((float)dq, red);
             const double m = sa / (double)N;
             double var = sq / (double)N - m * m;
             if (var < 0.0) var = 0.0;
@@ -279,8 +283,24 @@ extern "C" int kmu_bn_blend_fwd(const float* t, const float* x, const float* gam
         if (rc) return rc;
     }
     hipLaunchKernelGGL(bn_apply_kernel, dim3(C, sp.S), dim3(256), 0, st, t, x, gamma, beta, alpha, ws, running_mean,
-                       running_var, momentum, eps, relu, training, out, stats, num_batches_tracked, B, C, HW, sp.chunk);
+                       running_var, momentum, eps, relu, training, out, stats, num_batches_tracked, B, C, HW, sp.chunk, sp.S);
     return kmu::launch_status("bn_blend_fwd apply");
+}
+
+// Train-mode forward with the statistics partials ALREADY made by the kernel that produced t (kmu_dwconv3x3_fwd_stats,
+// kmu_pwconv_fwd_stats): stat_part [C][S_part][2] = per-workgroup (sum, sum of squares).  One launch instead of two.
+extern "C" int kmu_bn_blend_fwd_pre(const float* t, const float* x, const float* gamma, const float* beta, const float* alpha,
+                                    float* running_mean, float* running_var, float momentum, float eps, int relu, float* out,
+                                    float* stats, const float* stat_part, int S_part, long long* num_batches_tracked, int B, int C,
+                                    int HW, kmu_stream_t stream) {
+    KMU_REQUIRE(t && out && gamma && beta && running_mean && running_var && stats && stat_part && S_part > 0,
+                "bn_blend_fwd_pre: null pointer / no partials");
+    KMU_REQUIRE(!alpha || x, "bn_blend_fwd_pre: a blend needs x");
+    KMU_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0, "bn_blend_fwd_pre: bad dims");
+    const Split sp = split_for(B, HW);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(C, sp.S), dim3(256), 0, (hipStream_t)stream, t, x, gamma, beta, alpha, stat_part,
+                       running_mean, running_var, momentum, eps, relu, 1, out, stats, num_batches_tracked, B, C, HW, sp.chunk, S_part);
+    return kmu::launch_status("bn_blend_fwd_pre");
 }
 
 extern "C" int kmu_bn_blend_bwd(const float* gout, const float* t, const float* x, const float* gamma, const float* beta,

@@ -18,12 +18,18 @@ namespace {
 
 constexpr int WSPLIT = 4;  // row splits per (b, c) plane in the weight-gradient kernel
 
+// STATS: additionally leave per-workgroup (sum, sum of squares) of the outputs for the BatchNorm that follows (EfficientViMBlock's
+// dwconv1 / dwconv2, efficient_vim_init.py:85,93): the host only uses it when a workgroup's 1024 outputs lie in ONE (b, c) plane
+// (H*W % 1024 == 0, no grid-stride wrap), so stat_part[(c*S + b*(HW/1024) + k)*2 + {0,1}] is this block's pair -- the layout
+// kmu_bn_blend_fwd_pre folds.  Saves the separate statistics pass (one launch and one read of the tensor).
+template <bool STATS>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         const float* __restrict__ addend, float* __restrict__ out, int C, int H,
-                                                        int W, int flip, size_t total) {
+                                                        int W, int flip, size_t total, float* __restrict__ stat_part, int S) {
     const int W4 = (W + 3) >> 2;
     const bool vec_ok = (W & 3) == 0;
+    float st_a = 0.f, st_q = 0.f;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int x0 = (int)(t % W4) * 4;
         size_t r = t / W4;
@@ -70,6 +76,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
             for (int q = 0; q < 4; ++q)
                 if (x0 + q < W) acc[q] += ap[q];
         }
+        if (STATS) {
+            st_a += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            st_q += (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+        }
         float* dst = out + (r * H + y) * (size_t)W + x0;
         if (vec_ok) {
             *reinterpret_cast<floatx4*>(dst) = floatx4{acc[0], acc[1], acc[2], acc[3]};
@@ -77,6 +87,20 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (x0 + q < W) dst[q] = acc[q];
+        }
+    }
+    if (STATS) {
+        __shared__ float red[2][4];
+        st_a = kmu::wave_sum(st_a);
+        st_q = kmu::wave_sum(st_q);
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = st_a, red[1][threadIdx.x >> 6] = st_q;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int bpp = H * W / 1024;                         // blocks per plane
+            const int plane = blockIdx.x / bpp, k = blockIdx.x - plane * bpp, b = plane / C, c = plane - b * C;
+            float* p = stat_part + ((size_t)c * S + b * bpp + k) * 2;
+            p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         }
     }
 }
@@ -193,7 +217,8 @@ int launch_stencil(const float* in, const float* w, const float* bias, const flo
     const size_t total = (size_t)B * C * H * ((W + 3) / 4);
     size_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, scale, addend, out, C, H, W, flip, total);
+    hipLaunchKernelGGL(dwconv3x3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, scale, addend, out, C, H, W, flip,
+                       total, (float*)nullptr, 0);
     return kmu::launch_status(what);
 }
 
@@ -204,6 +229,23 @@ extern "C" int kmu_dwconv3x3_fwd(const float* x, const float* weight, const floa
     KMU_REQUIRE(x && weight && y, "dwconv3x3_fwd: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_fwd: bad dims");
     return launch_stencil(x, weight, bias, nullptr, y, B, C, H, W, 0, (hipStream_t)stream, "dwconv3x3_fwd");
+}
+
+// forward + the BatchNorm statistics partials of y: returns the number of partial pairs per channel S (stat_part [C][S][2], for
+// kmu_bn_blend_fwd_pre), or 0 when the shape does not allow it (then nothing was launched: use kmu_dwconv3x3_fwd)
+extern "C" int kmu_dwconv3x3_stats_partials(int B, int C, int H, int W) {
+    const long hw = (long)H * W;
+    return (W % 4 == 0 && hw % 1024 == 0 && (long)B * C * (hw / 1024) <= 16384) ? (int)(B * (hw / 1024)) : 0;
+}
+extern "C" int kmu_dwconv3x3_fwd_stats(const float* x, const float* weight, const float* bias, float* y, float* stat_part, int B, int C,
+                                       int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && weight && y && stat_part, "dwconv3x3_fwd_stats: null pointer");
+    const int S = kmu_dwconv3x3_stats_partials(B, C, H, W);
+    KMU_REQUIRE(B > 0 && C > 0 && S > 0, "dwconv3x3_fwd_stats: [%d,%d,%d,%d] is not covered (H*W %% 1024, W %% 4)", B, C, H, W);
+    const size_t total = (size_t)B * C * H * (W / 4);
+    hipLaunchKernelGGL(dwconv3x3_kernel<true>, dim3((unsigned)(total / 256)), dim3(256), 0, (hipStream_t)stream, x, weight, bias,
+                       (const float*)nullptr, (const float*)nullptr, y, C, H, W, 0, total, stat_part, S);
+    return kmu::launch_status("dwconv3x3_fwd_stats");
 }
 
 extern "C" int kmu_dwconv3x3_bwd_data(const float* dy, const float* weight, float* dx, int B, int C, int H, int W,

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
                                                       long w_sk, const float* __restrict__ bias,
                                                       const float* __restrict__ mul_pre, const float* __restrict__ addend,
                                                       float* __restrict__ y, int K, int N, int P, int act_in, int G, long w_sg,
-                                                      const float* __restrict__ bscale) {
+                                                      const float* __restrict__ bscale, float* __restrict__ stat_part) {
     // G > 1: grouped convolution (block-diagonal weights): x has G*K channels, y has N = G*Ng channels, tile n0 belongs to group
     // n0 / Ng and contracts that group's K input channels with w + g*w_sg indexed by the LOCAL output channel
     extern __shared__ float wl[];
@@ -113,10 +113,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     }
 
     // epilogue: lane owns channel n0 + 16nt + m, pixels p0 + 16i + 4q + t
+    float sta[NT], stq[NT];     // stat_part: (sum, sum of squares) of this lane's 16 outputs per channel tile, for the BatchNorm behind
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + 16 * nt + m;
         const float bv = bias ? bias[n] : 0.f;
+        sta[nt] = stq[nt] = 0.f;
         const float sc = bscale ? bscale[b] : 1.f;       // per-sample factor (DropPath's mask / keep_prob of a residual branch)
         const size_t off = ((size_t)b * N + n) * P + p0 + 4 * q;
 #pragma unroll
@@ -129,7 +131,37 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
             }
             if (bscale) o *= sc;
             if (addend) o += *reinterpret_cast<const floatx4*>(addend + off + 16 * i);
+            sta[nt] += (o[0] + o[1]) + (o[2] + o[3]);
+            stq[nt] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
             *reinterpret_cast<floatx4*>(y + off + 16 * i) = o;
+        }
+    }
+    if (stat_part) {            // host guarantees P % 256 == 0 (no wave left early): one (sum, sumsq) pair per workgroup and channel
+        __syncthreads();        // every wave is done with the weight tile: wl is scratch now
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float a = sta[nt], qq = stq[nt];
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            qq += __shfl_xor(qq, 16);
+            qq += __shfl_xor(qq, 32);
+            if (q == 0) {
+                wl[((wave * NT + nt) * 16 + m) * 2] = a;
+                wl[((wave * NT + nt) * 16 + m) * 2 + 1] = qq;
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 16) {
+            const int nt = tid >> 4, mm = tid & 15;
+            float a = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                a += wl[((w4 * NT + nt) * 16 + mm) * 2];
+                qq += wl[((w4 * NT + nt) * 16 + mm) * 2 + 1];
+            }
+            float* pp = stat_part + ((size_t)(n0 + 16 * nt + mm) * gridDim.x + blockIdx.x) * 2;
+            pp[0] = a;
+            pp[1] = qq;
         }
     }
 }
@@ -365,17 +397,18 @@ inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
 
 template <int NT>
 int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, const float* addend,
-                float* y, int B, int K, int N, int P, int act_in, hipStream_t st, int G, long w_sg, const float* bscale) {
+                float* y, int B, int K, int N, int P, int act_in, hipStream_t st, int G, long w_sg, const float* bscale,
+                float* stat_part) {
     const size_t lds = (size_t)K * lds_stride(NT) * sizeof(float);
     KMU_MAX_LDS((pw_gemm_kernel<NT>), lds);
     hipLaunchKernelGGL((pw_gemm_kernel<NT>), dim3(B * ((P + 255) / 256), N / (16 * NT)), dim3(256), lds, st, x, w, w_sn, w_sk, bias,
-                       mul_pre, addend, y, K, N, P, act_in, G, w_sg, bscale);
+                       mul_pre, addend, y, K, N, P, act_in, G, w_sg, bscale, stat_part);
     return 0;
 }
 
 int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y,
          int B, int K, int N, int P, int act_in, hipStream_t st, const float* addend = nullptr, int G = 1, long w_sg = 0,
-         const float* bscale = nullptr) {
+         const float* bscale = nullptr, float* stat_part = nullptr) {
     // K = contraction channels PER GROUP, N = output channels in total (G groups of N / G)
     KMU_REQUIRE(B > 0 && K > 0 && N > 0 && K % 16 == 0 && N % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16",
                 what, K, N);
@@ -389,10 +422,10 @@ int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk,
     const long blocks_x = (long)B * ((P + 255) / 256);
     while (nt > 1 && blocks_x * (N / (16 * nt)) < 192) nt = (nt == 4) ? 2 : 1;
     switch (nt) {
-        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
-        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
-        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
-        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale); break;
+        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
+        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
+        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
+        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
     }
     return kmu::launch_status(what);
 }
@@ -450,6 +483,18 @@ extern "C" int kmu_pwconv_bwd_input_s(const float* gy, const float* w, const flo
     KMU_REQUIRE(!act_in || x_pre, "pwconv_bwd_input_s: act_in needs the pre-activation input");
     return gemm("pwconv_bwd_input_s", gy, w, 1, Ci, nullptr, act_in ? x_pre : nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream, nullptr, 1, 0,
                 bscale);
+}
+
+// forward + the BatchNorm statistics partials of y (EfficientViMBlock's FFN: ConvLayer2D = 1x1 conv + BatchNorm2d,
+// vim_utils_init.py:62-89): stat_part [Co][S][2] with S = kmu_pwconv_stats_partials(B, P) workgroups per channel, the layout
+// kmu_bn_blend_fwd_pre folds.  0 partials = shape not covered (P % 256 != 0).
+extern "C" int kmu_pwconv_stats_partials(int B, int P) { return (P > 0 && P % 256 == 0) ? B * (P / 256) : 0; }
+extern "C" int kmu_pwconv_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stat_part, int B, int Ci, int Co,
+                                    int P, int act_in, kmu_stream_t stream) {
+    KMU_REQUIRE(x && w && y && stat_part, "pwconv_fwd_stats: null pointer");
+    KMU_REQUIRE(kmu_pwconv_stats_partials(B, P) > 0, "pwconv_fwd_stats: H*W = %d must be a multiple of 256", P);
+    return gemm("pwconv_fwd_stats", x, w, Ci, 1, bias, nullptr, y, B, Ci, Co, P, act_in, (hipStream_t)stream, nullptr, 1, 0, nullptr,
+                stat_part);
 }
 
 extern "C" size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P) {

@@ -1266,6 +1266,37 @@ def _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, relu, traini
     return out, stats
 
 
+def _k_bn_fwd_pre(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, relu, nbt, part, S):
+    """Train-mode BatchNorm (+ReLU / blend) whose statistics partials were left by the kernel that produced t: one launch."""
+    B, C = t.shape[:2]
+    HW = t.numel() // (B * C)
+    out = torch.empty_like(t)
+    stats = torch.empty(C, 2, device=t.device, dtype=torch.float32)
+    _lib.check(_call(("bn_blend_fwd_pre", (B, C, HW)), lib.kmu_bn_blend_fwd_pre, _ptr(t), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(a_row),
+                     _ptr(rm), _ptr(rv), float(momentum), float(eps), int(relu), _ptr(out), _ptr(stats), _ptr(part), S, _ptr(nbt), B, C, HW,
+                     _stream()), "kmu_bn_blend_fwd_pre")
+    if relu and a_row is None:
+        _tap_relu(out)
+    return out, stats
+
+
+def _k_pw_fwd_bn(lib, x, w, x_blend, gamma, beta, a_row, rm, rv, momentum, eps, relu, training, nbt):
+    """1x1 conv -> BatchNorm (-> ReLU / blend): in train mode the conv leaves the statistics partials (csrc/pwconv.hip)."""
+    B, ci, H, W = x.shape
+    co, P = w.shape[0], H * W
+    S = lib.kmu_pwconv_stats_partials(B, P) if training else 0
+    if not S:
+        z = _k_pw_fwd(lib, x, w)
+        out, stats = _k_bn_fwd(lib, z, x_blend, gamma, beta, a_row, rm, rv, momentum, eps, relu, training, nbt)
+        return z, out, stats
+    z = torch.empty(B, co, H, W, device=x.device, dtype=torch.float32)
+    part = torch.empty(co * S * 2, device=x.device, dtype=torch.float32)
+    _lib.check(_call(("pwconv_fwd", (B, ci, co, P)), lib.kmu_pwconv_fwd_stats, _ptr(x), _ptr(w), None, _ptr(z), _ptr(part), B, ci, co, P, 0,
+                     _stream()), "kmu_pwconv_fwd_stats")
+    out, stats = _k_bn_fwd_pre(lib, z, x_blend, gamma, beta, a_row, rm, rv, momentum, eps, relu, nbt, part, S)
+    return z, out, stats
+
+
 def _k_bn_bwd(lib, g, t, x, gamma, beta, a_row, stats, relu, training):
     B, C = t.shape[:2]
     HW = t.numel() // (B * C)
@@ -1308,9 +1339,16 @@ class DwBnBlendFn(torch.autograd.Function):
         x, w, a_row = _f32c(x, "x"), _f32c(w_dw, "weight"), _f32c(a_row, "alpha row")
         B, C, H, W = x.shape
         t = torch.empty_like(x)
-        _lib.check(_call(("dwconv3x3_fwd", (B, C, H, W)), lib.kmu_dwconv3x3_fwd, _ptr(x), _ptr(w), None, _ptr(t), B, C, H, W, _stream()),
-                   "kmu_dwconv3x3_fwd")
-        out, stats = _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, 0, training, nbt)
+        S = lib.kmu_dwconv3x3_stats_partials(B, C, H, W) if training else 0
+        if S:       # the stencil leaves the BatchNorm statistics partials: no separate statistics pass
+            part = torch.empty(C * S * 2, device=x.device, dtype=torch.float32)
+            _lib.check(_call(("dwconv3x3_fwd", (B, C, H, W)), lib.kmu_dwconv3x3_fwd_stats, _ptr(x), _ptr(w), None, _ptr(t), _ptr(part), B, C,
+                             H, W, _stream()), "kmu_dwconv3x3_fwd_stats")
+            out, stats = _k_bn_fwd_pre(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, 0, nbt, part, S)
+        else:
+            _lib.check(_call(("dwconv3x3_fwd", (B, C, H, W)), lib.kmu_dwconv3x3_fwd, _ptr(x), _ptr(w), None, _ptr(t), B, C, H, W, _stream()),
+                       "kmu_dwconv3x3_fwd")
+            out, stats = _k_bn_fwd(lib, t, x, gamma, beta, a_row, rm, rv, momentum, eps, 0, training, nbt)
         ctx.save_for_backward(x, w, t, gamma, beta, a_row, stats)
         ctx.cfg = (int(training), tuple(w_dw.shape))
         return out
@@ -1349,10 +1387,8 @@ class FfnBlendFn(torch.autograd.Function):
         x, a_row = _f32c(x, "x"), _f32c(a_row, "alpha row")
         hid, C = w1.shape[0], w1.shape[1]
         w1c, w2c = _f32c(w1, "fc1 weight").view(hid, C), _f32c(w2, "fc2 weight").view(C, hid)
-        z1 = _k_pw_fwd(lib, x, w1c)
-        h, st1 = _k_bn_fwd(lib, z1, None, g1, b1, None, rm1, rv1, mom1, eps1, 1, training, nbt1)
-        z2 = _k_pw_fwd(lib, h, w2c)
-        out, st2 = _k_bn_fwd(lib, z2, x, g2, b2, a_row, rm2, rv2, mom2, eps2, 0, training, nbt2)
+        z1, h, st1 = _k_pw_fwd_bn(lib, x, w1c, None, g1, b1, None, rm1, rv1, mom1, eps1, 1, training, nbt1)
+        z2, out, st2 = _k_pw_fwd_bn(lib, h, w2c, x, g2, b2, a_row, rm2, rv2, mom2, eps2, 0, training, nbt2)
         ctx.save_for_backward(x, w1c, z1, st1, h, w2c, z2, st2, g1, b1, g2, b2, a_row)
         ctx.cfg = (int(training), tuple(w1.shape), tuple(w2.shape))
         return out

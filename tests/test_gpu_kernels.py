@@ -774,12 +774,13 @@ def test_conv3tap_vs_torch_cpu(B, C, Co, H, W, axis):
 
 
 def test_colsum_multi_vs_torch():
-    """csrc/colsum.hip: ragged row / column counts, 1..8 arrays per launch, deterministic."""
+    """csrc/colsum.hip: ragged row / column counts, 1..64 arrays per launch, deterministic."""
     ops = _ops()
     gen = torch.Generator().manual_seed(11)
     shapes = [(1, 1), (7, 27), (1024, 100), (33, 3, 5), (8, 1), (129, 64), (2, 31), (500, 33)]
     parts = [torch.randn(*s, generator=gen).to(DEV) for s in shapes]
-    for n in (1, 3, 8):
+    parts = parts * 8                       # 64 arrays: the capacity of one launch
+    for n in (1, 3, 8, 64):
         outs = ops.colsum(*parts[:n])
         for p, o in zip(parts[:n], outs):
             assert o.shape == p.shape[1:]
@@ -789,7 +790,7 @@ def test_colsum_multi_vs_torch():
     mixed = ops.colsum(parts[0], None, parts[1])
     assert mixed[1] is None and rel_err(mixed[2], parts[1].double().sum(0)) < 1e-5
     with pytest.raises(RuntimeError):
-        ops.colsum(*(parts + parts[:1]))        # 9 arrays
+        ops.colsum(*(parts + parts[:1]))        # 65 arrays
 
 
 # ------------------------------------------------------------------------------------------ blocks

@@ -25,14 +25,38 @@ specs = {
     "evim16": (lambda: m.enc1[1].height_block.vit_mamba, [(B, 16, 128, 128)]),
     "evim32": (lambda: m.enc2[1].height_block.vit_mamba, [(B, 32, 64, 64)]),
     "evim64": (lambda: m.enc3[1].height_block.vit_mamba, [(B, 64, 32, 32)]),
+    "vimdec32": (lambda: m.dec2[2], [(B, 32, 64, 64)]),
+    "iwp2": (lambda: m.enc2[2], [(B, 32, 64, 64)]),
+    "lca1": (lambda: m.lca1, [(B, 16, 64, 64)]),
+    "kan2": (lambda: m.enc2[0], [(B, 16, 64, 64)]),
+    "kan3": (lambda: m.enc3[0], [(B, 32, 32, 32)]),
+    "deckan": (lambda: m.dec1[1], [(B, 64, 32, 32)]),
+    "up1": (lambda: m.dec1[0], [(B, 64, 16, 16)]),
+    "up2": (lambda: m.dec2[0], [(B, 64, 32, 32)]),
+    "up3": (lambda: m.dec3[0], [(B, 64, 64, 64)]),
+    "msf1": (lambda: m.attention1[0], None),
 }
 for name in sys.argv[1:]:
     mod, shapes = specs[name][0](), specs[name][1]
-    xs = [torch.randn(*s, device=dev, requires_grad=True) for s in shapes]
+    if shapes is None:       # MultiScaleFusion takes a list of three features
+        feats = [torch.randn(B, c, 32, 32, device=dev, requires_grad=True) for c in (16, 32, 32)]
+        xs, inner = feats, mod
+        mod = lambda *f: inner(list(f))
+        mod.parameters = inner.parameters
+    else:
+        xs = [torch.randn(*s, device=dev, requires_grad=True) for s in shapes]
     params = [p for p in mod.parameters() if p.requires_grad]
+    from km_unet_amd import ops
+    defer = os.environ.get("TB_DEFER", "1") == "1"      # weight gradients queued and flushed at the end, as in the train step
     def step():
         y = mod(*xs)
-        return torch.autograd.grad(y.float().square().mean(), xs + params, allow_unused=True)
+        ops.WGRAD_OVERLAP = defer
+        try:
+            g = torch.autograd.grad(y.float().square().mean(), xs + params, allow_unused=True)
+        finally:
+            ops.WGRAD_OVERLAP = False
+            ops.flush_wgrad_jobs(final=True)
+        return g
     for _ in range(3):
         step()
     torch.cuda.synchronize()
