@@ -15,14 +15,20 @@ using kmu::floatx4;
 
 namespace {
 
-constexpr int MAXS = 32;
+#ifndef KMU_BN_MAXS
+#define KMU_BN_MAXS 32
+#endif
+#ifndef KMU_BN_CHUNK
+#define KMU_BN_CHUNK 4096
+#endif
+constexpr int MAXS = KMU_BN_MAXS;
 
 struct Split {
     int S, chunk;  // S blocks per channel, each `chunk` (multiple of 4) flattened (b,p) positions
 };
 inline Split split_for(int B, int HW) {
     const long n = (long)B * HW;
-    int S = (int)((n + 4095) / 4096);
+    int S = (int)((n + KMU_BN_CHUNK - 1) / KMU_BN_CHUNK);
     if (S < 1) S = 1;
     if (S > MAXS) S = MAXS;
     long chunk = (n + S - 1) / S;
@@ -212,15 +218,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ d_gamma, float* __restrict__ d_beta,
                                                            float* __restrict__ d_alpha, int B, int C, int HW,
                                                            int chunk) {
+    __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     const long N = (long)B * HW, n0 = (long)s * chunk, n1 = min(N, n0 + chunk);
-    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-    for (int i = 0; i < S; ++i) {
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    for (int i = threadIdx.x; i < S; i += 256) {
         const float* p = part + ((size_t)c * S + i) * 3;
-        p0 += p[0];
-        p1 += p[1];
-        p2 += p[2];
+        q0 += p[0];
+        q1 += p[1];
+        q2 += p[2];
     }
+    const double p0 = (double)block_sum((float)q0, red), p1 = (double)block_sum((float)q1, red), p2 = (double)block_sum((float)q2, red);
     const float mean = gamma ? stats[c * 2] : 0.f, rstd = gamma ? stats[c * 2 + 1] : 1.f;
     const float g = gamma ? gamma[c] : 1.f, bt = gamma ? beta[c] : 0.f;
     const float a = alpha ? 1.f / (1.f + __expf(-alpha[c])) : 1.f;

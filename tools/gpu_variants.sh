@@ -5,7 +5,7 @@ PAT=$1; shift
 for v in "$@"; do
   R=/tmp/kmu_var_$v; rm -rf $R
   if [ "$v" = base ]; then unset KMU_LIB_VARIANT; else export KMU_LIB_VARIANT=$v; fi
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R -o v -- python3 tools/run_k2_shapes.py 10 > $O/$v.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R -o v -- python3 ${RUNNER:-tools/run_k2_shapes.py} 10 > $O/$v.log 2>&1
   rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT $v"; exit 1; fi
   ST=$(find $R -name "*kernel_stats.csv" | head -1)
   echo "== $v"; grep "done" $O/$v.log
