@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void conv3x3_x3_wgrad_kernel(const float* __re
                                                                int Cin, int Cout, int H, int W, int OT, int S, int tilesX,
                                                                int tilesY) {
     using G = Geo<WG_TH, WG_TW, KSZ>;
-    constexpr int RS = G::RS, HT = G::HT, NPIX = WG_TH * WG_TW, R = G::R, T = KSZ * KSZ, TG = (T + 8) / 9;
+    constexpr int RS = G::RS, HT = G::HT, R = G::R, T = KSZ * KSZ, TG = (T + 8) / 9;
     static_assert(MODE != MODE_KAN || KSZ == 3, "KANConv2d is 3x3");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* F = smem;
