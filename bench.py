@@ -99,9 +99,24 @@ def _kernel_model(name, shape):
         flops = 2.0 * B * P * Ci * Co
         extra = B * P * Ci if name.endswith("bwd_input") else 0     # GELU'(x_pre) operand (upper bound: only with gelu_in)
         return "hbm", flops, t * (B * P * (Ci + Co) + Ci * Co) + 0 * extra
+    if name.startswith("bn_blend_fwd_pre"):
+        B, C, HW = shape
+        return "hbm", 0.0, t * B * C * HW * 3                      # t once (the conv left the statistics), x, out
     if name.startswith("bn_blend"):
         B, C, HW = shape
         return "hbm", 0.0, t * B * C * HW * (4 if name.endswith("fwd") else 7)   # fwd: t twice (stats, apply), x, out
+    if name.startswith("triple_norm"):
+        B, C, HW = shape
+        return "hbm", 0.0, t * B * C * HW * (3 if name.endswith("fwd") else 6)   # fwd: x twice, y; bwd: x, dy twice, addend, dx
+    if name.startswith("mean_rows"):
+        B, C, HW = shape
+        return "hbm", 0.0, t * B * C * HW
+    if name.startswith("lca_"):
+        B, C, HW = shape
+        return "hbm", 0.0, t * B * C * HW * (2 if name.endswith("fwd") else 3)
+    if name.startswith("dagem_edges"):
+        B, C, H, W = shape
+        return "hbm", 0.0, t * B * C * H * W * (5 if name.endswith("fwd") else 6)
     if name.startswith("dwconv3x3"):
         B, C, H, W = shape[:4] if len(shape) >= 4 else (shape[0], shape[1], 1, 1)
         return "hbm", 18.0 * B * C * H * W, t * B * C * H * W * 2
