@@ -465,11 +465,14 @@ int kmu_bn_blend_fwd_pre(const float* t, const float* x, const float* gamma, con
 
 /* ------------------------------------------------------------------------------------
  * kmu_pwconv_bwd_weight in two halves, for callers that collect many weight gradients (a train step's weight-gradient tail is
- * bound by its launch count): the slab pass of one gradient into its workspace (kmu_pwconv_bwd_weight_ws_bytes), and the slab
- * reduction of up to 32 of them in one launch.  kmu_colsum_multi likewise takes up to 64 arrays.
+ * bound by its launch count): the slab pass of one gradient into its workspace (kmu_pwconv_bwd_weight_ws_bytes) -- or of up to 8
+ * gradients of identical dimensions in one launch (_partial_multi) -- and the slab reduction of up to 32 of them in one launch.
+ * kmu_colsum_multi likewise takes up to 64 arrays.
  * ------------------------------------------------------------------------------------ */
 int kmu_pwconv_bwd_weight_partial(const float* x, const float* gy, void* ws, size_t ws_bytes, int with_bias, int B, int Ci, int Co, int P,
                                   int act_in, kmu_stream_t stream);
+int kmu_pwconv_bwd_weight_partial_multi(int n, const float* const* x, const float* const* gy, void* const* ws, size_t ws_bytes,
+                                        int with_bias, int B, int Ci, int Co, int P, int act_in, kmu_stream_t stream);
 int kmu_pwconv_bwd_weight_reduce_multi(int n, const void* const* ws, float* const* dw, float* const* dbias, const int* B, const int* Ci,
                                        const int* Co, const int* P, kmu_stream_t stream);
 

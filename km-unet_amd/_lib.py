@@ -124,6 +124,7 @@ SIGNATURES = {
     "kmu_mix3_bwd_dg_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),
     "kmu_mix3_bwd_apply_stacked": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "kmu_pwconv_bwd_weight_partial": (_I, [_P] * 3 + [_Z] + [_I] * 6 + [_P]),
+    "kmu_pwconv_bwd_weight_partial_multi": (_I, [_I] + [_P] * 3 + [_Z] + [_I] * 6 + [_P]),
     "kmu_pwconv_bwd_weight_reduce_multi": (_I, [_I] + [_P] * 7 + [_P]),
     "kmu_dwconv3x3_stats_partials": (_I, [_I] * 4),
     "kmu_dwconv3x3_fwd_stats": (_I, [_P] * 5 + [_I] * 4 + [_P]),

@@ -190,10 +190,21 @@ __device__ __forceinline__ void wgrad_load(floatx4 (&a)[MT][2], floatx4 (&bx)[NT
     }
 }
 
+// blockIdx.z selects one of up to WMAX problems of IDENTICAL dimensions (the same layer of several modules -- the three direction
+// branches, the two blocks of a level): one launch with z times the workgroups instead of z launches
+constexpr int WMAX = 8;
+struct WgradMulti {
+    const float* x[WMAX];
+    const float* gy[WMAX];
+    float* slab[WMAX];
+    float* bslab[WMAX];
+};
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                       float* __restrict__ slab, float* __restrict__ bslab, int Ci, int Co,
-                                                       int P, int nchunks, int act_in, int XC, int GC) {
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradMulti pm, int Ci, int Co, int P, int nchunks, int act_in, int XC, int GC) {
+    const float* __restrict__ x = pm.x[blockIdx.z];
+    const float* __restrict__ gy = pm.gy[blockIdx.z];
+    float* __restrict__ slab = pm.slab[blockIdx.z];
+    float* __restrict__ bslab = pm.bslab[blockIdx.z];
     __shared__ floatx4 red[3][MT * NT][64];
     __shared__ float bred[3][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -431,20 +442,18 @@ int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk,
 }
 
 template <int MT, int NT>
-void launch_wgrad(const WgradPlan& pl, const float* x, const float* gy, float* slab, float* bslab, int Ci, int Co, int P, int act_in,
-                  hipStream_t st, int XC, int GC) {
-    hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), dim3(pl.G, pl.nsp), dim3(256), 0, st, x, gy, slab, bslab, Ci, Co, P, pl.nchunks,
-                       act_in, XC, GC);
+void launch_wgrad(const WgradPlan& pl, const WgradMulti& pm, int nprob, int Ci, int Co, int P, int act_in, hipStream_t st, int XC, int GC) {
+    hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), dim3(pl.G, pl.nsp, nprob), dim3(256), 0, st, pm, Ci, Co, P, pl.nchunks, act_in, XC, GC);
 }
 
 template <int MT>
-void launch_wgrad_nt(const WgradPlan& pl, const float* x, const float* gy, float* slab, float* bslab, int Ci, int Co, int P,
-                     int act_in, hipStream_t st, int XC, int GC) {
+void launch_wgrad_nt(const WgradPlan& pl, const WgradMulti& pm, int nprob, int Ci, int Co, int P, int act_in, hipStream_t st, int XC,
+                     int GC) {
     switch (pl.NT) {
-        case 4: launch_wgrad<MT, 4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
-        case 3: launch_wgrad<MT, 3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
-        case 2: launch_wgrad<MT, 2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
-        default: launch_wgrad<MT, 1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        case 4: launch_wgrad<MT, 4>(pl, pm, nprob, Ci, Co, P, act_in, st, XC, GC); break;
+        case 3: launch_wgrad<MT, 3>(pl, pm, nprob, Ci, Co, P, act_in, st, XC, GC); break;
+        case 2: launch_wgrad<MT, 2>(pl, pm, nprob, Ci, Co, P, act_in, st, XC, GC); break;
+        default: launch_wgrad<MT, 1>(pl, pm, nprob, Ci, Co, P, act_in, st, XC, GC); break;
     }
 }
 
@@ -514,11 +523,13 @@ static int pw_bwd_weight(const char* what, const float* x, const float* gy, floa
                 (pl.slab_floats + pl.bslab_floats) * sizeof(float));
     float* slab = (float*)ws;
     float* bslab = dbias ? slab + pl.slab_floats : nullptr;
+    WgradMulti pm;
+    pm.x[0] = x, pm.gy[0] = gy, pm.slab[0] = slab, pm.bslab[0] = bslab;
     switch (pl.MT) {
-        case 4: launch_wgrad_nt<4>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
-        case 3: launch_wgrad_nt<3>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
-        case 2: launch_wgrad_nt<2>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
-        default: launch_wgrad_nt<1>(pl, x, gy, slab, bslab, Ci, Co, P, act_in, st, XC, GC); break;
+        case 4: launch_wgrad_nt<4>(pl, pm, 1, Ci, Co, P, act_in, st, XC, GC); break;
+        case 3: launch_wgrad_nt<3>(pl, pm, 1, Ci, Co, P, act_in, st, XC, GC); break;
+        case 2: launch_wgrad_nt<2>(pl, pm, 1, Ci, Co, P, act_in, st, XC, GC); break;
+        default: launch_wgrad_nt<1>(pl, pm, 1, Ci, Co, P, act_in, st, XC, GC); break;
     }
     int rc = kmu::launch_status(what);
     if (rc || !reduce) return rc;
@@ -535,6 +546,30 @@ extern "C" int kmu_pwconv_bwd_weight_partial(const float* x, const float* gy, vo
     float dummy;
     return pw_bwd_weight("pwconv_bwd_weight_partial", x, gy, nullptr, with_bias ? &dummy : nullptr, ws, ws_bytes, B, Ci, Co, P, act_in,
                          (hipStream_t)stream, Ci, Co, false);
+}
+
+// the slab pass of n <= 8 weight gradients of IDENTICAL dimensions in one launch (problem i: x[i], gy[i] -> ws[i])
+extern "C" int kmu_pwconv_bwd_weight_partial_multi(int n, const float* const* x, const float* const* gy, void* const* ws, size_t ws_bytes,
+                                                   int with_bias, int B, int Ci, int Co, int P, int act_in, kmu_stream_t stream) {
+    KMU_REQUIRE(n > 0 && n <= WMAX && x && gy && ws, "pwconv_bwd_weight_partial_multi: %d problems (1..%d)", n, WMAX);
+    KMU_REQUIRE(B > 0 && Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0 && P > 0 && P % 32 == 0,
+                "pwconv_bwd_weight_partial_multi: bad dims (%d -> %d, H*W = %d)", Ci, Co, P);
+    const WgradPlan pl = wgrad_plan(B, Ci, Co, P);
+    KMU_REQUIRE(ws_bytes >= (pl.slab_floats + pl.bslab_floats) * sizeof(float), "pwconv_bwd_weight_partial_multi: workspace too small");
+    WgradMulti pm;
+    for (int i = 0; i < n; ++i) {
+        KMU_REQUIRE(x[i] && gy[i] && ws[i], "pwconv_bwd_weight_partial_multi: problem %d has a null pointer", i);
+        pm.x[i] = x[i], pm.gy[i] = gy[i], pm.slab[i] = (float*)ws[i];
+        pm.bslab[i] = with_bias ? (float*)ws[i] + pl.slab_floats : nullptr;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (pl.MT) {
+        case 4: launch_wgrad_nt<4>(pl, pm, n, Ci, Co, P, act_in, st, Ci, Co); break;
+        case 3: launch_wgrad_nt<3>(pl, pm, n, Ci, Co, P, act_in, st, Ci, Co); break;
+        case 2: launch_wgrad_nt<2>(pl, pm, n, Ci, Co, P, act_in, st, Ci, Co); break;
+        default: launch_wgrad_nt<1>(pl, pm, n, Ci, Co, P, act_in, st, Ci, Co); break;
+    }
+    return kmu::launch_status("pwconv_bwd_weight_partial_multi");
 }
 
 extern "C" int kmu_pwconv_bwd_weight_reduce_multi(int n, const void* const* ws, float* const* dw, float* const* dbias, const int* B,

@@ -84,6 +84,7 @@ def _ptr(t):
 WGRAD_OVERLAP = False
 WGRAD_BATCH = int(os.environ.get("KMU_WGRAD_BATCH", "4096"))
 WGRAD_STREAMS = int(os.environ.get("KMU_WGRAD_STREAMS", "3"))
+WGRAD_GROUP = os.environ.get("KMU_WGRAD_GROUP", "1") == "1"     # identical pointwise-conv weight gradients share a launch
 _WG_SIDE = {}
 _WG_JOBS = []
 _WG_BUSY = set()
@@ -129,11 +130,13 @@ def flush_wgrad_jobs(final=True):
                 side.wait_event(ev)
             _WG_BUSY.add(side)
         global _WG_BATCH
-        batch = _WG_BATCH = {"colsum": [], "pwred": []} if final else None
+        batch = _WG_BATCH = {"colsum": [], "pwred": [], "pw": []} if final else None
         try:
             for i, (_, job) in enumerate(_WG_JOBS):
                 with torch.cuda.stream(sides[i % len(sides)]):
                     job()
+            if batch and batch["pw"]:
+                _issue_pw_partials(batch, sides)
         finally:
             _WG_BATCH = None
         _WG_JOBS.clear()        # inputs die here: their blocks go back to the producers' pools, whose next kernels are ordered
@@ -178,9 +181,36 @@ def _pw_wgrad_call(lib, x, gy, dw, db, B, ci, co, P, act_in):
         _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight, _ptr(x), _ptr(gy), _ptr(dw), _ptr(db), _ptr(ws),
                          nbytes, B, ci, co, P, int(act_in), _stream()), "kmu_pwconv_bwd_weight")
         return
-    _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight_partial, _ptr(x), _ptr(gy), _ptr(ws), nbytes,
-                     int(db is not None), B, ci, co, P, int(act_in), _stream()), "kmu_pwconv_bwd_weight_partial")
-    _WG_BATCH["pwred"].append((ws, dw, db, B, ci, co, P))
+    # only registered: problems of identical dimensions (the same layer of the three branches / the two blocks of a level) share a
+    # launch (_issue_pw_partials), and every slab reduction shares one (_issue_batched)
+    if WGRAD_GROUP:
+        _WG_BATCH["pw"].append((x, gy, ws, dw, db, B, ci, co, P, int(act_in)))
+    else:
+        _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight_partial, _ptr(x), _ptr(gy), _ptr(ws), nbytes,
+                         int(db is not None), B, ci, co, P, int(act_in), _stream()), "kmu_pwconv_bwd_weight_partial")
+        _WG_BATCH["pwred"].append((ws, dw, db, B, ci, co, P))
+
+
+def _issue_pw_partials(batch, lanes):
+    """slab passes of the registered pointwise-conv weight gradients, up to 8 identical problems per launch, dealt over `lanes`"""
+    import ctypes
+    lib = _lib.load()
+    groups = {}
+    for pr in batch["pw"]:
+        groups.setdefault((pr[5], pr[6], pr[7], pr[8], pr[9], pr[4] is not None), []).append(pr)
+    k = 0
+    for (B, ci, co, P, act_in, has_b), prs in groups.items():
+        nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)
+        for i in range(0, len(prs), 8):
+            ch = prs[i:i + 8]
+            n = len(ch)
+            vp = ctypes.c_void_p * n
+            with torch.cuda.stream(lanes[k % len(lanes)]):
+                _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight_partial_multi, n,
+                                 vp(*[c[0].data_ptr() for c in ch]), vp(*[c[1].data_ptr() for c in ch]), vp(*[c[2].data_ptr() for c in ch]),
+                                 nbytes, int(has_b), B, ci, co, P, act_in, _stream()), "kmu_pwconv_bwd_weight_partial_multi")
+            k += 1
+            batch["pwred"].extend((c[2], c[3], c[4], B, ci, co, P) for c in ch)
 
 
 def _issue_batched(batch):
