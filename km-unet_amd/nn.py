@@ -341,13 +341,16 @@ class _SkinnyLinearFn(torch.autograd.Function):
     (113 us at N = 131072, rocprof) -- as a product and a column sum it is two streaming launches (~12 us)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)      # fp32 inside whatever autocast says outside
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         return torch.addmm(b, x, w.t())
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        dy = dy.float()
         return dy @ w, (x * dy).sum(0, keepdim=True), dy.sum(0)
 
 

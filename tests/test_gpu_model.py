@@ -342,3 +342,22 @@ def test_grouped_branches_match_separate(monkeypatch, C, hw):
     print("  [grouped branches C=%d %dx%d] y=%.2e dx=%.2e worst parameter gradient %.2e (%s) running stats %.2e" % (
         C, hw, hw, e_y, e_dx, worst[1], worst[0], e_buf))
     assert e_y < 1e-5 and e_dx < 1e-4 and worst[1] < 1e-4 and e_buf < 1e-5
+
+
+def test_model_under_autocast_and_half_input():
+    """The reference's callers wrap the model in torch.cuda.amp.autocast() and feed .half() inputs at test time
+    (train_shanghai.py:159-215, :242): the HIP path computes in fp32 whatever arrives (ops._f32c), the remaining ATen glue may run
+    in fp16 under autocast -- the result must stay finite, close to the fp32 run, and differentiable."""
+    m = _build("SH", 5, True)
+    x = torch.rand(2, 5, 64, 64, generator=torch.Generator().manual_seed(51)).cuda()
+    tgt = torch.rand(2, 5, 64, 64, generator=torch.Generator().manual_seed(52)).cuda()
+    y32 = m(x)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y16 = m(x.half())
+        loss = torch.nn.functional.mse_loss(y16.float(), tgt)
+    loss.backward()
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
+    e = rel_err(y16.float(), y32)
+    print("  [autocast] output vs fp32 run %.2e, %d parameter gradients" % (e, len(grads)))
+    assert torch.isfinite(y16).all() and e < 2e-2
+    assert len(grads) == 664 and all(torch.isfinite(g).all() for g in grads)
