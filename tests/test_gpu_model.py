@@ -361,3 +361,28 @@ def test_model_under_autocast_and_half_input():
     print("  [autocast] output vs fp32 run %.2e, %d parameter gradients" % (e, len(grads)))
     assert torch.isfinite(y16).all() and e < 2e-2
     assert len(grads) == 664 and all(torch.isfinite(g).all() for g in grads)
+
+
+@pytest.mark.parametrize("variant,nc,size,check", [("SH", 5, 96, True), ("LAPS", 7, 96, True), ("SH", 5, 480, False), ("SH", 3, 72, True)])
+def test_train_step_at_other_sizes(variant, nc, size, check):
+    """Sizes whose coarse levels miss the fast paths' divisibility rules (96 -> 12x12 tokens, 72 -> 9x9 with odd planes, 480 -> 60x60:
+    BASELINE configs[4]): every op must either take its general path or a stock one -- train-mode forward + backward stay finite,
+    all 664 live parameters get a gradient, and (small sizes) the eval forward matches the CPU oracle."""
+    import km_unet_amd
+    from oracle.model import KM_UNetV3 as Oracle, fill_parameters
+    o = fill_parameters(Oracle(num_classes=nc, variant=variant), 9)
+    m = km_unet_amd.KM_UNetV3(num_classes=nc, variant=variant)
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.cuda()
+    x = torch.rand(1 if size > 128 else 2, 5, size, size, generator=torch.Generator().manual_seed(size))
+    if check:           # before the train-mode step moves the BatchNorm running statistics
+        with torch.no_grad():
+            e = rel_err(m.eval()(x.cuda()), o.eval()(x))
+        print("  [%s %dx%d] eval forward vs oracle %.2e" % (variant, size, size, e))
+        assert e < TOL
+    m.train()
+    y = m(x.cuda())
+    y.square().mean().backward()
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
+    assert torch.isfinite(y).all() and all(torch.isfinite(g).all() for g in grads)
+    assert len(grads) == (664 if variant == "SH" else len(grads))
