@@ -386,3 +386,42 @@ def test_train_step_at_other_sizes(variant, nc, size, check):
     grads = [p.grad for p in m.parameters() if p.grad is not None]
     assert torch.isfinite(y).all() and all(torch.isfinite(g).all() for g in grads)
     assert len(grads) == (664 if variant == "SH" else len(grads))
+
+
+def test_reference_style_training_iterations():
+    """Two iterations exactly as train_shanghai.py runs them (:159-181, :333-342, :398-415): data[B,T,1,H,W] -> squeeze -> input /
+    target slices, autocast forward + HybridLoss, GradScaler-scaled backward into .grad (AccumulateGrad, not the flat bucket),
+    AdamW over model.parameters(), CosineAnnealingLR -- through the drop-in import path."""
+    import sys, os
+    import km_unet_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(km_unet_amd.__file__), "dropin"))
+    try:
+        from KM_UNetV3_SH import KM_UNetV3
+    finally:
+        sys.path.pop(0)
+    from km_unet_amd.loss import HybridLoss
+    torch.manual_seed(0)
+    model = KM_UNetV3(num_classes=5).cuda()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200, eta_min=5e-4)
+    scaler = torch.amp.GradScaler("cuda")
+    crit = HybridLoss().cuda()
+    data = torch.rand(2, 10, 1, 64, 64, generator=torch.Generator().manual_seed(61)).cuda()
+    before = [p.detach().clone() for p in model.parameters()]
+    losses = []
+    for it in range(2):
+        model.train()
+        d = data.squeeze(2)
+        inp, tgt = d[:, :5], d[:, 5:]
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = model(inp)
+            loss = crit(out.float(), tgt.float())
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        sched.step()
+        losses.append(loss.item())
+    moved = sum(1 for a, p in zip(before, model.parameters()) if not torch.equal(a, p.detach()))
+    print("  [reference-style loop] losses %s, %d / %d parameter tensors moved" % (["%.4f" % l for l in losses], moved, len(before)))
+    assert all(l == l and l < 10 for l in losses) and moved >= 664
