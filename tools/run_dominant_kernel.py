@@ -43,5 +43,17 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     y.backward(g64)
     z = ops.dw_bn_blend(xg, type("C", (), {"weight": wdw})(), bn, alpha)   # dwconv3x3 + BN(train) + blend: fwd / bwd
     z.backward(gy)
+# EnhancedViMBlock's tail as one node (TripleNorm + FFN + residual) and the small round-2 glue kernels
+C = 16
+tn = [torch.randn(C, device=d, requires_grad=True) for _ in range(6)]
+w0, b0 = (torch.randn(4 * C, C, 1, 1, device=d) * 0.2).requires_grad_(True), torch.zeros(4 * C, device=d, requires_grad=True)
+w2, b2 = (torch.randn(C, 4 * C, 1, 1, device=d) * 0.2).requires_grad_(True), torch.zeros(C, device=d, requires_grad=True)
+gate = torch.rand(B, C, device=d, requires_grad=True)
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    o = ops.VimTailFn.apply(xg, *tn, 1e-5, 1e-5, w0, b0, w2, b2, None)
+    o.backward(gy)
+    l = ops.lca_apply(xg, gate)
+    l.backward(gy)
+    m3 = ops.spatial_mean(xg)
 torch.cuda.synchronize()
 print("glue done")
