@@ -99,6 +99,12 @@ def _kernel_model(name, shape):
         flops = 2.0 * B * P * Ci * Co
         extra = B * P * Ci if name.endswith("bwd_input") else 0     # GELU'(x_pre) operand (upper bound: only with gelu_in)
         return "hbm", flops, t * (B * P * (Ci + Co) + Ci * Co) + 0 * extra
+    if name.startswith("ffn_"):       # csrc/ffn_fused.hip: [B,C,P] tensors read / written once per pass, 4C hidden channels recomputed
+        B, C, P = shape
+        prod = 2.0 * B * P * C * 4 * C                               # one C x 4C product over all pixels
+        tensors, nprod = {"ffn_fwd_stats": (1, 1), "ffn_fwd_main": (2, 2), "ffn_fwd_apply": (3, 0), "ffn_bwd_red": (3, 0),
+                          "ffn_bwd_mid": (3, 3), "ffn_bwd_in": (4, 4)}[name]
+        return "hbm", nprod * prod, t * B * C * P * tensors
     if name.startswith("bn_blend_fwd_pre"):
         B, C, HW = shape
         return "hbm", 0.0, t * B * C * HW * 3                      # t once (the conv left the statistics), x, out

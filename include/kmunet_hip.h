@@ -563,6 +563,35 @@ int kmu_mix3_bwd_dg_stacked(const float* dy, const float* F, const float* g, con
 int kmu_mix3_bwd_apply_stacked(const float* dy, const float* g, const float* s, const float* d_pooled, float* dF, int B, int C, int HW,
                                kmu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * EfficientViMBlock's FFN stage as recompute kernels (round 3):
+ *     out = x + sigmoid(alpha) * ( BN2( W2 relu( BN1( W1 x ) ) ) - x )
+ * efficient_vim_init.py:96 (the blend), vim_utils_init.py:122-130 (FFN = fc1, fc2) and :62-89 (ConvLayer2D = bias-free 1x1 conv +
+ * BatchNorm2d [+ ReLU]).  x [B,C,P] with C in {16, 32, 64}, W1 [4C,C], W2 [C,4C], P = H*W a multiple of 64 (kmu_ffn_fused_supported;
+ * other shapes: kmu_pwconv_* + kmu_bn_blend_*).  Nothing 4C wide reaches memory: every pass re-derives W1 x from x on the matrix core.
+ *   fwd stages: 0 statistics of W1 x (train only), 1 z2 = W2 relu(BN1(W1 x)) + its statistics, 2 out; stage -1 = all.
+ *               Saved for backward: x, z2, stats1 [4C][2], stats2 [C][2] (mean, rstd).  Running statistics / num_batches_tracked are
+ *               updated as nn.BatchNorm2d does (train).  h_tap (NULL in production): the hidden activation [B,4C,P], for tests.
+ *   bwd stages: 0 BN2's backward sums, 1 BN1's backward sums + dW2 slabs, 2 dx + dW1 slabs; stage -1 = all.  training = 0: BatchNorm
+ *               backward without the batch-mean terms (eval-mode statistics).
+ *               slab_w1 [rows][4C][C], slab_w2 [rows][C][4C] with rows = kmu_ffn_fused_rows: per-workgroup partial weight gradients,
+ *               d W = their column sum (kmu_colsum_multi).
+ * ------------------------------------------------------------------------------------ */
+int kmu_ffn_fused_supported(int C, int hid, int P);
+int kmu_ffn_fused_rows(int B, int C, int P);
+size_t kmu_ffn_fused_fwd_ws_bytes(int B, int C, int P);
+size_t kmu_ffn_fused_bwd_ws_bytes(int B, int C, int P);
+int kmu_ffn_fused_fwd(const float* x, const float* w1, const float* gamma1, const float* beta1, float* running_mean1,
+                      float* running_var1, long long* nbt1, float momentum1, float eps1, const float* w2, const float* gamma2,
+                      const float* beta2, float* running_mean2, float* running_var2, long long* nbt2, float momentum2, float eps2,
+                      const float* alpha, int training, float* z2, float* out, float* stats1, float* stats2, float* h_tap, void* ws,
+                      size_t ws_bytes, int B, int C, int P, int stage, kmu_stream_t stream);
+int kmu_ffn_fused_bwd(const float* g, const float* x, const float* z2, const float* w1, const float* gamma1, const float* beta1,
+                      const float* stats1, const float* w2, const float* gamma2, const float* beta2, const float* stats2,
+                      const float* alpha, int training, float* dx, float* d_gamma1, float* d_beta1, float* d_gamma2, float* d_beta2,
+                      float* d_alpha, float* slab_w1, float* slab_w2, void* ws, size_t ws_bytes, int B, int C, int P, int stage,
+                      kmu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1445,6 +1445,77 @@ class FfnBlendFn(torch.autograd.Function):
         return (dx, dw1.view(s1), dg1, db1, None, None, None, None, None, dw2.view(s2), dg2, db2, None, None, None, None, None, da, None)
 
 
+# The FFN stage as recompute kernels (csrc/ffn_fused.hip): nothing 4C wide is stored.  KMU_FFN_FUSED=0 keeps the pointwise-conv +
+# BatchNorm kernels (FfnBlendFn), which also serve the shapes the fused kernels do not cover (C not in {16, 32, 64}, H*W % 64 != 0).
+FFN_FUSED = os.environ.get("KMU_FFN_FUSED", "1") == "1"
+_FFN_STAGES_F = ("ffn_fwd_stats", "ffn_fwd_main", "ffn_fwd_apply")
+_FFN_STAGES_B = ("ffn_bwd_red", "ffn_bwd_mid", "ffn_bwd_in")
+
+
+class FfnFusedFn(torch.autograd.Function):
+    """x + sigmoid(a) (BN2(fc2(ReLU(BN1(fc1(x))))) - x), EfficientViMBlock's FFN stage (efficient_vim_init.py:96; FFN = two bias-free
+    1x1 ConvLayer2D, vim_utils_init.py:62-89,122-130), as 3 + 3 recompute launches: saved for backward are x, z2 = fc2(...) and the two
+    BatchNorms' (mean, rstd) -- no 4C-wide tensor, forward or backward; both weight gradients leave per-workgroup slabs whose column
+    sums run off the activation-gradient chain."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, mom1, eps1, nbt1, w2, g2, b2, rm2, rv2, mom2, eps2, nbt2, a_row, training):
+        ctx.defer_wgrad = _leaf(w1, w2)
+        lib = _lib.load()
+        x, a_row = _f32c(x, "x"), _f32c(a_row, "alpha row")
+        B, C, H, W = x.shape
+        P, hid, dev = H * W, w1.shape[0], x.device
+        w1c, w2c = _f32c(w1, "fc1 weight").view(hid, C), _f32c(w2, "fc2 weight").view(C, hid)
+        g1, b1, g2, b2 = _f32c(g1, "bn1 weight"), _f32c(b1, "bn1 bias"), _f32c(g2, "bn2 weight"), _f32c(b2, "bn2 bias")
+        z2, out = torch.empty_like(x), torch.empty_like(x)
+        st1 = torch.empty(hid, 2, device=dev, dtype=torch.float32)
+        st2 = torch.empty(C, 2, device=dev, dtype=torch.float32)
+        nbytes = lib.kmu_ffn_fused_fwd_ws_bytes(B, C, P)
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        h = torch.empty(B, hid, H, W, device=dev, dtype=torch.float32) if RELU_TAP is not None else None
+        tr = int(bool(training))
+        st = _stream()
+        for stage, nm in enumerate(_FFN_STAGES_F):
+            if stage == 0 and not tr:
+                continue
+            _lib.check(_call((nm, (B, C, P)), lib.kmu_ffn_fused_fwd, _ptr(x), _ptr(w1c), _ptr(g1), _ptr(b1), _ptr(rm1), _ptr(rv1),
+                             _ptr(nbt1 if tr else None), float(mom1), float(eps1), _ptr(w2c), _ptr(g2), _ptr(b2), _ptr(rm2), _ptr(rv2),
+                             _ptr(nbt2 if tr else None), float(mom2), float(eps2), _ptr(a_row), tr, _ptr(z2), _ptr(out), _ptr(st1),
+                             _ptr(st2), _ptr(h), _ptr(ws), nbytes, B, C, P, stage, st), "kmu_ffn_fused_fwd")
+        if h is not None:
+            _tap_relu(h)
+        ctx.save_for_backward(x, z2, w1c, w2c, g1, b1, g2, b2, st1, st2, a_row)
+        ctx.cfg = (tr, tuple(w1.shape), tuple(w2.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, z2, w1, w2, g1, b1, g2, b2, st1, st2, a_row = ctx.saved_tensors
+        tr, s1, s2 = ctx.cfg
+        g = _f32c(g, "grad")
+        B, C, H, W = x.shape
+        P, hid, dev = H * W, w1.shape[0], x.device
+        rows = lib.kmu_ffn_fused_rows(B, C, P)
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        dx, dg1, db1, dg2, db2, da = torch.empty_like(x), mk(hid), mk(hid), mk(C), mk(C), mk(C)
+        slab1, slab2 = mk(rows, hid * C), mk(rows, C * hid)
+        nbytes = lib.kmu_ffn_fused_bwd_ws_bytes(B, C, P)
+        ws = mk(nbytes // 4)
+        st = _stream()
+        for stage, nm in enumerate(_FFN_STAGES_B):
+            _lib.check(_call((nm, (B, C, P)), lib.kmu_ffn_fused_bwd, _ptr(g), _ptr(x), _ptr(z2), _ptr(w1), _ptr(g1), _ptr(b1), _ptr(st1),
+                             _ptr(w2), _ptr(g2), _ptr(b2), _ptr(st2), _ptr(a_row), tr, _ptr(dx), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2),
+                             _ptr(da), _ptr(slab1), _ptr(slab2), _ptr(ws), nbytes, B, C, P, stage, st), "kmu_ffn_fused_bwd")
+        dw1, dw2 = mk(hid, C), mk(C, hid)
+        _wgrad(lambda: colsum(slab1, slab2, outs=[dw1.view(-1), dw2.view(-1)]), ctx.defer_wgrad)
+        return (dx, dw1.view(s1), dg1, db1, None, None, None, None, None, dw2.view(s2), dg2, db2, None, None, None, None, None, da, None)
+
+
+def ffn_fused_supported(C, hid, P):
+    return FFN_FUSED and bool(_lib.load().kmu_ffn_fused_supported(C, hid, P))
+
+
 def _bn_pack(bn):
     training = bn.training
     nbt = bn.num_batches_tracked if training and bn.track_running_stats else None
@@ -1459,6 +1530,9 @@ def dw_bn_blend(x, conv, bn, a_row):
 def ffn_blend(x, fc1, fc2, a_row):
     g1, b1, rm1, rv1, mom1, eps1, nbt1, training = _bn_pack(fc1.norm)
     g2, b2, rm2, rv2, mom2, eps2, nbt2, _ = _bn_pack(fc2.norm)
+    if x.is_cuda and ffn_fused_supported(x.shape[1], fc1.conv.out_channels, x.shape[2] * x.shape[3]) and fc2.conv.out_channels == x.shape[1]:
+        return FfnFusedFn.apply(x, fc1.conv.weight, g1, b1, rm1, rv1, mom1, eps1, nbt1, fc2.conv.weight, g2, b2, rm2, rv2, mom2, eps2, nbt2,
+                                a_row, training)
     return FfnBlendFn.apply(x, fc1.conv.weight, g1, b1, rm1, rv1, mom1, eps1, nbt1, fc2.conv.weight, g2, b2, rm2, rv2, mom2, eps2, nbt2, a_row,
                             training)
 

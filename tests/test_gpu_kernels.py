@@ -793,6 +793,94 @@ def test_colsum_multi_vs_torch():
         ops.colsum(*(parts + parts[:1]))        # 65 arrays
 
 
+
+@pytest.mark.parametrize("B,C,H,W,train", [(2, 16, 32, 32, True), (8, 16, 128, 128, True), (3, 16, 8, 24, True), (2, 32, 16, 16, True),
+                                           (8, 32, 64, 64, True), (2, 64, 8, 8, True), (8, 64, 32, 32, True), (1, 64, 8, 16, True),
+                                           (2, 16, 32, 32, False), (2, 32, 16, 16, False), (2, 64, 16, 16, False)])
+def test_ffn_fused_vs_torch_cpu(B, C, H, W, train):
+    """EfficientViMBlock's FFN stage (efficient_vim_init.py:96, vim_utils_init.py:62-89,122-130) as the recompute kernels
+    (csrc/ffn_fused.hip) against torch fp64 on the CPU: x + sigmoid(a) (BN2(fc2(relu(BN1(fc1 x)))) - x), forward, every gradient,
+    the running statistics and the batch counters; and the hidden ReLU mask the kernels report equals the fp64 one except where the
+    pre-activation is within rounding of zero."""
+    import copy
+    import torch.nn as nn
+    import km_unet_amd
+    ops = _ops()
+    gen = torch.Generator().manual_seed(7 * C + H)
+    ffn = km_unet_amd.nn.FFN(C, 4 * C)
+    with torch.no_grad():
+        for conv in (ffn.fc1.conv, ffn.fc2.conv):
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * 0.4)
+        for bn in (ffn.fc1.norm, ffn.fc2.norm):
+            bn.weight.copy_(1 + 0.3 * torch.randn(bn.weight.shape, generator=gen)); bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, generator=gen))
+            bn.running_mean.copy_(0.1 * torch.randn(bn.bias.shape, generator=gen)); bn.running_var.copy_(0.5 + torch.rand(bn.bias.shape, generator=gen))
+    alpha = torch.randn(C, generator=gen)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.5 + 0.3
+    gy = torch.randn(B, C, H, W, generator=gen)
+    # fp64 reference: stock modules
+    ref = nn.Sequential(nn.Conv2d(C, 4 * C, 1, bias=False), nn.BatchNorm2d(4 * C), nn.ReLU(), nn.Conv2d(4 * C, C, 1, bias=False),
+                        nn.BatchNorm2d(C)).double()
+    with torch.no_grad():
+        ref[0].weight.copy_(ffn.fc1.conv.weight); ref[3].weight.copy_(ffn.fc2.conv.weight)
+        for r, bn in ((ref[1], ffn.fc1.norm), (ref[4], ffn.fc2.norm)):
+            r.weight.copy_(bn.weight); r.bias.copy_(bn.bias); r.running_mean.copy_(bn.running_mean); r.running_var.copy_(bn.running_var)
+    ref.train(train)
+    xo, ao = x.double().requires_grad_(True), alpha.double().requires_grad_(True)
+    pre = ref[1](ref[0](xo))
+    yo = torch.lerp(xo, ref[4](ref[3](torch.relu(pre))), torch.sigmoid(ao).view(1, C, 1, 1))
+    yo.backward(gy.double())
+    fd = copy.deepcopy(ffn).to(DEV).train(train)
+    xd, ad = x.to(DEV).requires_grad_(True), alpha.to(DEV).requires_grad_(True)
+    assert ops.ffn_fused_supported(C, 4 * C, H * W)
+    ops.RELU_TAP = []
+    try:
+        y = ops.ffn_blend(xd, fd.fc1, fd.fc2, ad)
+        mask = ops.RELU_TAP[0]
+    finally:
+        ops.RELU_TAP = None
+    assert y.grad_fn.__class__.__name__ == "FfnFusedFnBackward"
+    y.backward(gy.to(DEV))
+    flips = (mask != (pre.detach() > 0))
+    assert float(pre.detach().abs()[flips].max() if flips.any() else 0.0) < 1e-4 * float(pre.detach().abs().max())
+    errs = {"y": rel_err(y, yo), "dx": rel_err(xd.grad, xo.grad), "dalpha": rel_err(ad.grad, ao.grad),
+            "dw1": rel_err(fd.fc1.conv.weight.grad, ref[0].weight.grad), "dw2": rel_err(fd.fc2.conv.weight.grad, ref[3].weight.grad),
+            "dg1": rel_err(fd.fc1.norm.weight.grad, ref[1].weight.grad), "db1": rel_err(fd.fc1.norm.bias.grad, ref[1].bias.grad),
+            "dg2": rel_err(fd.fc2.norm.weight.grad, ref[4].weight.grad), "db2": rel_err(fd.fc2.norm.bias.grad, ref[4].bias.grad),
+            "rm1": rel_err(fd.fc1.norm.running_mean, ref[1].running_mean), "rv1": rel_err(fd.fc1.norm.running_var, ref[1].running_var),
+            "rm2": rel_err(fd.fc2.norm.running_mean, ref[4].running_mean), "rv2": rel_err(fd.fc2.norm.running_var, ref[4].running_var)}
+    assert int(fd.fc1.norm.num_batches_tracked) == int(ref[1].num_batches_tracked)
+    assert int(fd.fc2.norm.num_batches_tracked) == int(ref[4].num_batches_tracked)
+    _report("ffn_fused %s" % ((B, C, H, W, train),), **errs)
+    # same op twice: bit-identical (fixed-order reductions, no atomics)
+    xd2, ad2 = x.to(DEV).requires_grad_(True), alpha.to(DEV).requires_grad_(True)
+    fd2 = copy.deepcopy(ffn).to(DEV).train(train)
+    y2 = ops.ffn_blend(xd2, fd2.fc1, fd2.fc2, ad2)
+    y2.backward(gy.to(DEV))
+    assert torch.equal(y2, y) and torch.equal(xd2.grad, xd.grad) and torch.equal(fd2.fc1.conv.weight.grad, fd.fc1.conv.weight.grad)
+
+
+def test_ffn_fused_matches_unfused_kernels(monkeypatch):
+    """The recompute kernels against the pointwise-conv + BatchNorm kernels they replace (FfnBlendFn), same inputs, train mode."""
+    import copy
+    import km_unet_amd
+    ops = _ops()
+    gen = torch.Generator().manual_seed(3)
+    B, C, H, W = 4, 32, 32, 32
+    ffn = km_unet_amd.nn.FFN(C, 4 * C)
+    with torch.no_grad():
+        ffn.fc2.norm.weight.copy_(1 + 0.3 * torch.randn(C, generator=gen))
+    alpha = torch.randn(C, generator=gen)
+    x, gy = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FFN_FUSED", fused)
+        f = copy.deepcopy(ffn).to(DEV).train()
+        xd, ad = x.to(DEV).requires_grad_(True), alpha.to(DEV).requires_grad_(True)
+        y = ops.ffn_blend(xd, f.fc1, f.fc2, ad)
+        y.backward(gy.to(DEV))
+        res.append((y, xd.grad, ad.grad, f.fc1.conv.weight.grad, f.fc2.conv.weight.grad, f.fc1.norm.weight.grad, f.fc2.norm.bias.grad))
+    _report("ffn fused vs unfused", **{n: rel_err(a, b) for n, a, b in zip(("y", "dx", "da", "dw1", "dw2", "dg1", "db2"), res[0], res[1])})
+
 # ------------------------------------------------------------------------------------------ blocks
 @pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
 def test_evim_block_golden(name, train):
