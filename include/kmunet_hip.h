@@ -574,11 +574,11 @@ int kmu_mix3_bwd_apply_stacked(const float* dy, const float* g, const float* s, 
  *               updated as nn.BatchNorm2d does (train).  h_tap (NULL in production): the hidden activation [B,4C,P], for tests.
  *   bwd stages: 0 BN2's backward sums, 1 BN1's backward sums + dW2 slabs, 2 dx + dW1 slabs; stage -1 = all.  training = 0: BatchNorm
  *               backward without the batch-mean terms (eval-mode statistics).
- *               slab_w1 [rows][4C][C], slab_w2 [rows][C][4C] with rows = kmu_ffn_fused_rows: per-workgroup partial weight gradients,
+ *               slab_w1 [rows1][4C][C], slab_w2 [rows2][C][4C] with rows = kmu_ffn_fused_rows(.., 1 / 2): partial weight gradients,
  *               d W = their column sum (kmu_colsum_multi).
  * ------------------------------------------------------------------------------------ */
 int kmu_ffn_fused_supported(int C, int hid, int P);
-int kmu_ffn_fused_rows(int B, int C, int P);
+int kmu_ffn_fused_rows(int B, int C, int P, int which); /* which: 1 = rows of slab_w1, 2 = rows of slab_w2 */
 size_t kmu_ffn_fused_fwd_ws_bytes(int B, int C, int P);
 size_t kmu_ffn_fused_bwd_ws_bytes(int B, int C, int P);
 int kmu_ffn_fused_fwd(const float* x, const float* w1, const float* gamma1, const float* beta1, float* running_mean1,

@@ -143,7 +143,7 @@ SIGNATURES = {
     "kmu_pwconv_fwd_res": (_I, [_P] * 6 + [_I] * 5 + [_P]),
     "kmu_pwconv_bwd_input_s": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "kmu_ffn_fused_supported": (_I, [_I] * 3),
-    "kmu_ffn_fused_rows": (_I, [_I] * 3),
+    "kmu_ffn_fused_rows": (_I, [_I] * 4),
     "kmu_ffn_fused_fwd_ws_bytes": (_Z, [_I] * 3),
     "kmu_ffn_fused_bwd_ws_bytes": (_Z, [_I] * 3),
     "kmu_ffn_fused_fwd": (_I, [_P] * 7 + [_c.c_float] * 2 + [_P] * 6 + [_c.c_float] * 2 + [_P, _I] + [_P] * 6 + [_Z] + [_I] * 4 + [_P]),

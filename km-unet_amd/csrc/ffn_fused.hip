@@ -15,23 +15,28 @@
 //             B2  g, z2, x    -> dz2 -> dh = W2^T dz2 -> dr = dh * [h > 0]: partial sums of BN1's backward; dW2 = sum dz2 h^T (slabs)
 //             B3  g, z2, x    -> dz1 -> dx = W1^T dz1 + (1 - a) g; dW1 = sum dz1 x^T (slabs)
 //
-// A kernel that needs channel statistics finds the PARTIAL rows of the kernel before it (one row per workgroup, <= 256 rows) and every
-// workgroup reduces them itself in a fixed order (double) -- ~1-2 us of L2 reads at its start instead of a finalising launch (or an
-// in-kernel last-arriver with its agent-scope fences) on the dependent chain; workgroup 0 also writes the results out (saved
-// statistics, running statistics, parameter gradients).  z1 is accumulated in the same k order in F2, B2 and B3, so the ReLU branch
-// taken by the backward is bit-for-bit the forward's.
+// A kernel that needs channel statistics finds the PARTIAL rows of the kernel before it and every workgroup reduces them itself in a
+// fixed order (double) -- L2 reads at its start instead of a finalising launch (or an in-kernel last-arriver with its agent-scope
+// fences) on the dependent chain; workgroup 0 also writes the results out (saved statistics, running statistics, parameter
+// gradients).  z1 is accumulated in the same k order in F2, B2 and B3, so the ReLU branch taken by the backward is bit-for-bit the
+// forward's.
 //
-// Orientations (one wave = 64 pixels x a slice of the hidden channels; lane = (n = l % 16, q = l / 16)):
-//   D'  (F1, B2, B3)  M = pixels, N = hidden j, K = channels: A = x loaded as float4 [c = 16c'+4q+s][p0 + 4f(n) .. +3], f(n) = n/4 + 4(n%4)
-//       (component t = tile t), B = W1[j][c].  D[t] register i <-> pixel p0 + 16i + 4q + t, column j on the lane: per-channel constants are
-//       ONE register per 16 channels, and dz (hidden) is directly the A operand of the weight-gradient product (rows j, k = pixel),
-//       whose B operand is x / dz2 loaded as float4 [c = lane%16][p0 + 16i + 4q .. +3].
-//       dx = dz1 W1 contracts over j (the lane index): dz1 takes one trip through LDS (T[j][pixel], 64-pixel rows + 16 B pad).
+// Work units.  One wave = one pixel tile (64 pixels; 32 at C = 64) x one SLICE of the hidden channels (all 64 at C = 16, 32 of 128 /
+// 256 at C = 32 / 64), 8 waves per workgroup, and at the bench shapes exactly one unit per wave (256 workgroups).
+//   tile-major  (F2, B3): the slices of a tile sit in ONE workgroup, because z2 = W2 h and dx = W1^T dz1 sum over all hidden channels
+//               (partial sums / the dz1 tile meet in LDS);
+//   slice-major (F1, B2): a workgroup is 8 tiles of ONE slice.  Nothing crosses slices there, the 8 waves share their weights, and the
+//               partial rows they leave are 1/JS as wide -- the consumer's fold of the hidden-channel statistics reads JS times fewer bytes.
+// Orientations (lane = (n = l % 16, q = l / 16), TT = float4 / float2 components = MFMA tiles per 16 rows):
+//   D'  (F1, B2, B3)  M = pixels, N = hidden j, K = channels: A = x loaded [c = 16c'+4q+s][p0 + TT f(n) .. ], f(n) = n/4 + 4(n%4)
+//       (component t = tile t), B = W1[j][c].  D[t] register i <-> pixel p0 + 4TT i + TT q + t, column j on the lane: per-channel constants
+//       are ONE register per 16 channels, and dz (hidden) is directly the A operand of the weight-gradient product (rows j, k = pixel),
+//       whose B operand is x / dz2 loaded [c = lane%16][p0 + 4TT i + TT q .. ].
+//       dx = dz1 W1 contracts over j (the lane index): dz1 takes one trip through LDS, 16 hidden channels at a time.
 //   N   (F2)          M = hidden j, N = pixels, K = channels: the result D1 (rows j in registers, pixel on the lane) is directly the
 //       B operand of z2 = W2 h (K = j) -- no LDS between the two products.
-// C = 16: 4 waves x their own 64-pixel tile, all 64 hidden channels per wave, no cross-wave traffic in the tile loop.
-// C = 32 / 64: ONE tile per workgroup iteration, the hidden channels split over 4 / 8 waves (32 each): 8 x fewer pixels per level
-// would otherwise leave most SIMDs idle; z2 partial sums (F2) and the dz1 tile (B3) meet in LDS.
+// The hidden tiles (16 channels) of a wave are processed one after the other in B2 / B3 (z1, dh, the element-wise step, the weight
+// gradient and the dx contribution of 16 channels at a time): ~190 registers instead of ~300, two waves per SIMD.
 #include "common.h"
 
 using kmu::floatx4;
@@ -40,18 +45,34 @@ namespace {
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
+#ifndef KMU_FFN_GMAX
+#define KMU_FFN_GMAX 256   // workgroups per kernel (tile-major: = partial rows; slice-major: rows = GMAX / JS)
+#endif
+#ifndef KMU_FFN_DBG
+#define KMU_FFN_DBG 0      // timing experiments only (tools/build_variant.py): 1 = skip the partial-row reduction (wrong results)
+#endif
+
+template <int TT> struct Vec;
+template <> struct Vec<4> { typedef floatx4 type; };
+template <> struct Vec<2> { typedef floatx2 type; };
+
 template <int C>
 struct Cfg {
     static constexpr int HID = 4 * C;
-    static constexpr int JS = C == 16 ? 1 : C / 8;     // hidden-channel slices per tile (= waves sharing a tile)
-    static constexpr int NW = C == 16 ? 4 : JS;        // waves per workgroup
-    static constexpr int NTW = HID / JS / 16;          // 16-channel hidden tiles per wave: 4, 2, 2
     static constexpr int CC = C / 16;                  // 16-channel chunks of C
-    static constexpr int TPI = C == 16 ? 4 : 1;        // tiles per workgroup iteration
+    static constexpr int JS = C == 16 ? 1 : C / 8;     // hidden-channel slices per tile
+    static constexpr int NTW = HID / JS / 16;          // 16-channel hidden tiles per wave: 4, 2, 2
+    static constexpr int SW = 16 * NTW;                // hidden channels per slice
+    static constexpr int TT = C == 64 ? 2 : 4;         // MFMA tiles (of 16 pixels) per unit
+    static constexpr int TP = 16 * TT;                 // pixels per tile
+    static constexpr int TS = TP + 4;                  // floats per LDS pixel row: vector-aligned, +4 banks per row
+    static constexpr int NW = 8;                       // waves per workgroup
     static constexpr int NTHR = NW * 64;
-    static constexpr int GMAX = C == 16 ? 256 : 128;   // workgroups (= partial rows): rows x 2 HID floats stays <= 256 KB per reader
+    static constexpr int TG = NW / JS;                 // tile-major: tiles per workgroup iteration
+    typedef typename Vec<TT>::type VT;
+    // column of (hidden channel j, kind) in a partial row of hidden-channel sums: [slice][kind][SW]
+    static __device__ __forceinline__ int col(int j, int kind) { return (j / SW) * 2 * SW + kind * SW + (j % SW); }
 };
-constexpr int TS = 68;   // floats per 64-pixel LDS row: 16-byte aligned, +4 banks per row
 
 // Every MFMA here is the tied-operand asm form (common.h): with the builtin, hipcc (ROCm 7.2) rotates these fully unrolled accumulator
 // sets through D != C register pairs and then re-writes the old C registers 4 wait states behind the MFMA that still reads them, and under
@@ -73,7 +94,13 @@ __device__ __forceinline__ void drain(floatx4 (&x)[N][M]) {
 #pragma unroll
         for (int j = 0; j < M; ++j) asm volatile("" : "+v"(x[i][j]));
 }
+template <int N>
+__device__ __forceinline__ void zero(floatx4 (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+}
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ int fperm(int n) { return (n >> 2) + 4 * (n & 3); }
 
 // Column sums of part[G][W] (fp32 rows of the previous kernel) in double and in a fixed order -> tot[W].  scratch: R * W doubles.
 template <int W, int NTHR>
@@ -83,6 +110,7 @@ struct RowReduce {
     static constexpr int SCRATCH = R * W;   // doubles
     static __device__ __forceinline__ void run(const float* __restrict__ part, int G, double* scratch, double* tot) {
         static_assert(NCG <= NTHR, "row wider than the workgroup");
+        if (KMU_FFN_DBG & 1) G = 1;
         const int tid = threadIdx.x, cg = tid % NCG, rg = tid / NCG;
         if (rg < R) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -154,96 +182,92 @@ __device__ __forceinline__ void load_w2r(const float* __restrict__ w2, int j0, i
             w2r[nt][k] = w2[(size_t)(16 * (k >> 2) + 4 * q + (k & 3)) * Cfg<C>::HID + j0 + 16 * nt + n];
 }
 
-// z1'[pixel][j] = sum_c x[c][pixel] W1[j][c] for one 64-pixel tile and this wave's hidden slice (orientation D').
-// xt = x + (b*C)*P + p0.  Accumulation order: chunks c' outer, s inner, the MFMA's own k = q innermost -- the SAME order as F2's.
+// Layout-A load of one tile: v[cc][s] = t[c = 16cc + 4q + s][p0 + TT f(n) ..]  (tt = t + (b*C)*P + p0)
 template <int C>
-__device__ __forceinline__ void fc1_dp(const float* __restrict__ xt, int P, const float (&w1r)[Cfg<C>::NTW][4 * Cfg<C>::CC],
-                                       floatx4 (&z1)[Cfg<C>::NTW][4], int n, int q) {
-    const int poff = 4 * ((n >> 2) + 4 * (n & 3));
+__device__ __forceinline__ void load_a(const float* __restrict__ tt, int P, typename Cfg<C>::VT (&v)[Cfg<C>::CC][4], int n, int q) {
+    typedef typename Cfg<C>::VT VT;
+    const int poff = Cfg<C>::TT * fperm(n);
 #pragma unroll
-    for (int nt = 0; nt < Cfg<C>::NTW; ++nt)
+    for (int cc = 0; cc < Cfg<C>::CC; ++cc)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) z1[nt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cc = 0; cc < Cfg<C>::CC; ++cc) {
-        floatx4 xa[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const floatx4*>(xt + (size_t)(16 * cc + 4 * q + s) * P + poff);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int nt = 0; nt < Cfg<C>::NTW; ++nt)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) mfma(z1[nt][t], xa[s][t], w1r[nt][4 * cc + s]);
-    }
-    drain(z1);
+        for (int s = 0; s < 4; ++s) v[cc][s] = *reinterpret_cast<const VT*>(tt + (size_t)(16 * cc + 4 * q + s) * P + poff);
 }
 
-// dh'[pixel][j] = sum_c dz2[c][pixel] W2[c][j] with dz2 = A_c g + (B_c z2 + D_c) formed on the fly (cst2[c] = {A, B, D, 1 - a} in LDS)
+// z1'[pixel][j] = sum_c x[c][pixel] W1[j][c] for one tile (xa: its layout-A image in registers) and ONE 16-channel hidden tile
+// (orientation D').  Accumulation order: chunks c' outer, s inner, the MFMA's own k = q innermost -- the SAME order as F2's.
+// Also serves dh'[pixel][j] = sum_c dz2[c][pixel] W2[c][j] (xa = dz2, w1row = this tile's W2 fragment).
 template <int C>
-__device__ __forceinline__ void dh_dp(const float* __restrict__ gt, const float* __restrict__ zt, int P, const floatx4* cst2,
-                                      const float (&w2r)[Cfg<C>::NTW][4 * Cfg<C>::CC], floatx4 (&dh)[Cfg<C>::NTW][4], int n, int q) {
-    const int poff = 4 * ((n >> 2) + 4 * (n & 3));
+__device__ __forceinline__ void fc1_dp(const typename Cfg<C>::VT (&xa)[Cfg<C>::CC][4], const float (&w1row)[4 * Cfg<C>::CC],
+                                       floatx4 (&z1)[Cfg<C>::TT]) {
+    using K = Cfg<C>;
+    zero(z1);
 #pragma unroll
-    for (int nt = 0; nt < Cfg<C>::NTW; ++nt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dh[nt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cc = 0; cc < Cfg<C>::CC; ++cc) {
-        floatx4 dz[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const size_t o = (size_t)(16 * cc + 4 * q + s) * P + poff;
-            const floatx4 gv = *reinterpret_cast<const floatx4*>(gt + o), zv = *reinterpret_cast<const floatx4*>(zt + o);
-            const floatx4 k = cst2[16 * cc + 4 * q + s];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dz[s][t] = fmaf(k[0], gv[t], fmaf(k[1], zv[t], k[2]));
-        }
+    for (int cc = 0; cc < K::CC; ++cc)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nt = 0; nt < Cfg<C>::NTW; ++nt)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) mfma(dh[nt][t], dz[s][t], w2r[nt][4 * cc + s]);
-    }
-    drain(dh);
+            for (int t = 0; t < K::TT; ++t) mfma(z1[t], xa[cc][s][t], w1row[4 * cc + s]);
+    drain(z1);
 }
 
 template <int C>
 __device__ __forceinline__ void tile_of(int tile, int P, int& b, int& p0) {
-    const int tpp = P >> 6;
+    const int tpp = P / Cfg<C>::TP;
     b = tile / tpp;
-    p0 = (tile - b * tpp) << 6;
+    p0 = (tile - b * tpp) * Cfg<C>::TP;
 }
 
-// ------------------------------------------------------------------------------------------------------------ F1
+
+// Slice-major workgroup -> (slice, row group r).  The JS workgroups of a row group read the SAME tiles; with b -> r = b%8 + 8 (b / (8 JS)),
+// slice = (b / 8) % JS they share blockIdx % 8, i.e. one XCD (and its L2) under the dispatcher's round-robin placement -- a speed
+// matter only (measured without it: 4x the fabric traffic at C = 32).  Grids that are not a multiple of 8 JS use the plain mapping.
+template <int JS>
+__device__ __forceinline__ void slice_major(int& slice, int& r, int& R) {
+    const int b = blockIdx.x, G = gridDim.x;
+    R = G / JS;
+    if (JS > 1 && G % (8 * JS) == 0) {
+        r = (b & 7) + 8 * (b / (8 * JS));
+        slice = (b >> 3) % JS;
+    } else {
+        slice = b % JS;
+        r = b / JS;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ F1 (slice-major)
+// grid = JS * R workgroups: slice = blockIdx % JS, r = blockIdx / JS; the 8 waves take 8 different tiles.  part1 [R][JS][2][SW].
 template <int C>
 __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_stats1_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                                   float* __restrict__ part1, int P, int ntiles) {
     using K = Cfg<C>;
-    __shared__ float comb[K::JS == 1 ? 4 * 2 * K::HID : 4];
+    __shared__ float comb[K::NW * 2 * K::SW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
-    const int j0 = K::JS == 1 ? 0 : wave * 16 * K::NTW;
+    int slice, r, R;
+    slice_major<K::JS>(slice, r, R);
+    const int j0 = slice * K::SW;
     float w1r[K::NTW][4 * K::CC];
     load_w1r<C>(w1, j0, n, q, w1r);
     float sa[K::NTW], sq[K::NTW];
 #pragma unroll
     for (int nt = 0; nt < K::NTW; ++nt) sa[nt] = sq[nt] = 0.f;
-    for (int tile = blockIdx.x * K::TPI + (K::JS == 1 ? wave : 0); tile < ntiles; tile += gridDim.x * K::TPI) {
+    for (int tile = r * K::NW + wave; tile < ntiles; tile += R * K::NW) {
         int b, p0;
         tile_of<C>(tile, P, b, p0);
-        floatx4 z1[K::NTW][4];
-        fc1_dp<C>(x + (size_t)b * C * P + p0, P, w1r, z1, n, q);
+        typename K::VT xa[K::CC][4];
+        load_a<C>(x + (size_t)b * C * P + p0, P, xa, n, q);
 #pragma unroll
-        for (int nt = 0; nt < K::NTW; ++nt)
+        for (int nt = 0; nt < K::NTW; ++nt) {
+            floatx4 z1[K::TT];
+            fc1_dp<C>(xa, w1r[nt], z1);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < K::TT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v = z1[nt][t][i];
+                    const float v = z1[t][i];
                     sa[nt] += v;
                     sq[nt] = fmaf(v, v, sq[nt]);
                 }
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < K::NTW; ++nt) {
@@ -251,29 +275,22 @@ __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_stats1_kernel(const float* _
         sa[nt] += __shfl_xor(sa[nt], 32);
         sq[nt] += __shfl_xor(sq[nt], 16);
         sq[nt] += __shfl_xor(sq[nt], 32);
-    }
-    float* row = part1 + (size_t)blockIdx.x * 2 * K::HID;
-    if constexpr (K::JS == 1) {
         if (q == 0) {
-#pragma unroll
-            for (int nt = 0; nt < K::NTW; ++nt) {
-                comb[wave * 2 * K::HID + 16 * nt + n] = sa[nt];
-                comb[wave * 2 * K::HID + K::HID + 16 * nt + n] = sq[nt];
-            }
+            comb[wave * 2 * K::SW + 16 * nt + n] = sa[nt];
+            comb[wave * 2 * K::SW + K::SW + 16 * nt + n] = sq[nt];
         }
-        __syncthreads();
-        for (int t = threadIdx.x; t < 2 * K::HID; t += K::NTHR)
-            row[t] = ((comb[t] + comb[2 * K::HID + t]) + comb[4 * K::HID + t]) + comb[6 * K::HID + t];
-    } else if (q == 0) {
+    }
+    __syncthreads();
+    float* row = part1 + ((size_t)r * K::JS + slice) * 2 * K::SW;
+    for (int t = threadIdx.x; t < 2 * K::SW; t += K::NTHR) {
+        float s = comb[t];
 #pragma unroll
-        for (int nt = 0; nt < K::NTW; ++nt) {
-            row[j0 + 16 * nt + n] = sa[nt];
-            row[K::HID + j0 + 16 * nt + n] = sq[nt];
-        }
+        for (int w = 1; w < K::NW; ++w) s += comb[w * 2 * K::SW + t];
+        row[t] = s;
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------ F2
+// ------------------------------------------------------------------------------------------------------------ F2 (tile-major)
 struct BnArgs {            // one BatchNorm2d's parameters / state
     const float* gamma;
     const float* beta;
@@ -287,7 +304,9 @@ template <int C>
 struct F2Lds {
     using K = Cfg<C>;
     static constexpr int RED_D = RowReduce<2 * K::HID, K::NTHR>::SCRATCH + 2 * K::HID;              // doubles (prologue)
-    static constexpr int MAIN_F = K::JS == 1 ? 4 * 2 * C : K::JS * C * TS;                          // floats (tile loop / epilogue)
+    static constexpr int RED_F = K::JS == 1 ? 4 : K::NW * C * K::TS;                                // z2 partial tiles of the slices
+    static constexpr int COMB_F = K::TG * 2 * C;                                                    // statistics rows of the tile groups
+    static constexpr int MAIN_F = RED_F > COMB_F ? RED_F : COMB_F;
     static constexpr size_t UNION_B = (size_t)RED_D * 8 > (size_t)MAIN_F * 4 ? (size_t)RED_D * 8 : (size_t)MAIN_F * 4;
     static constexpr size_t BYTES = 2 * K::HID * 4 + UNION_B;
 };
@@ -295,17 +314,18 @@ struct F2Lds {
 template <int C>
 __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_fwd_main_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                                     const float* __restrict__ w2, BnArgs bn1,
-                                                                    const float* __restrict__ part1, int G1, int training,
+                                                                    const float* __restrict__ part1, int R1, int training,
                                                                     float* __restrict__ stats1, float* __restrict__ z2,
                                                                     float* __restrict__ part2, float* __restrict__ h_tap, int P,
                                                                     int ntiles, double Ntot) {
     using K = Cfg<C>;
+    typedef typename K::VT VT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc1 = reinterpret_cast<float*>(smem);
     float* sh1 = sc1 + K::HID;
     char* un = smem + 2 * K::HID * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
-    const int j0 = K::JS == 1 ? 0 : wave * 16 * K::NTW;
+    const int grp = wave / K::JS, slice = wave % K::JS, j0 = slice * K::SW;
 
     // this wave's weights first: their round trip overlaps the statistics prologue
     float w1r[K::NTW][4 * K::CC];
@@ -316,15 +336,27 @@ __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_fwd_main_kernel(const float*
 #pragma unroll
         for (int nt = 0; nt < K::NTW; ++nt)
             w2r[ct][nt] = *reinterpret_cast<const floatx4*>(w2 + (size_t)(16 * ct + m) * K::HID + j0 + 16 * nt + 4 * q);
+    // the first tile's x is requested BEFORE the prologue: its HBM round trip overlaps the fold of the partial rows.
+    // xn[cc][s]: B[k = q][n = m] of the first product: channel 16cc + 4q + s, pixel p0 + TT m + t
+    const int per_it = gridDim.x * K::TG, unit0 = blockIdx.x * K::TG + grp;
+    VT xn[K::CC][4];
+    if (unit0 < ntiles) {
+        int b, p0;
+        tile_of<C>(unit0, P, b, p0);
+#pragma unroll
+        for (int cc = 0; cc < K::CC; ++cc)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xn[cc][s] = *reinterpret_cast<const VT*>(x + ((size_t)b * C + 16 * cc + 4 * q + s) * P + p0 + K::TT * m);
+    }
 
     if (training) {
         double* scratch = reinterpret_cast<double*>(un);
         double* tot = scratch + RowReduce<2 * K::HID, K::NTHR>::SCRATCH;
-        RowReduce<2 * K::HID, K::NTHR>::run(part1, G1, scratch, tot);
+        RowReduce<2 * K::HID, K::NTHR>::run(part1, R1, scratch, tot);
         for (int j = tid; j < K::HID; j += K::NTHR) {
             float mean, rstd;
             double var;
-            mean_rstd(tot[j], tot[K::HID + j], Ntot, bn1.eps, mean, rstd, var);
+            mean_rstd(tot[K::col(j, 0)], tot[K::col(j, 1)], Ntot, bn1.eps, mean, rstd, var);
             if (blockIdx.x == 0) {
                 stats1[2 * j] = mean, stats1[2 * j + 1] = rstd;
                 bn1.running_mean[j] = (1.f - bn1.momentum) * bn1.running_mean[j] + bn1.momentum * mean;
@@ -351,116 +383,153 @@ __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_fwd_main_kernel(const float*
     __syncthreads();                     // the union region turns from reduction scratch into tile scratch
 
     float* redz = reinterpret_cast<float*>(un);
-    // statistics of z2: JS == 1: lane (m, q) owns channels 16ct + 4q + i of its pixels; JS > 1: thread e / e + NTHR own channel e>>4
-    float s2a[K::JS == 1 ? 4 * K::CC : 2], s2q[K::JS == 1 ? 4 * K::CC : 2];
+    // statistics of z2: JS == 1: lane (m, q) owns channels 16ct + 4q + i of its pixels; JS > 1: thread e / e + JS*64 of the group own channel e>>4
+    constexpr int NS = K::JS == 1 ? 4 * K::CC : 2;
+    float s2a[NS], s2q[NS];
 #pragma unroll
-    for (int k = 0; k < (K::JS == 1 ? 4 * K::CC : 2); ++k) s2a[k] = s2q[k] = 0.f;
+    for (int k = 0; k < NS; ++k) s2a[k] = s2q[k] = 0.f;
+    const int gtid = tid - grp * K::JS * 64;             // thread index inside the tile group
 
-    for (int tile = blockIdx.x * K::TPI + (K::JS == 1 ? wave : 0); tile < ntiles; tile += gridDim.x * K::TPI) {
-        int b, p0;
-        tile_of<C>(tile, P, b, p0);
-        const float* xt = x + (size_t)b * C * P + p0;
-        floatx4 d1[K::NTW][4];
+    const int iters = (ntiles + per_it - 1) / per_it;
+    for (int it = 0; it < iters; ++it) {
+        const int tile = unit0 + it * per_it;
+        const bool valid = tile < ntiles;        // uniform over the tile group
+        int b = 0, p0 = 0;
+        if (valid) tile_of<C>(tile, P, b, p0);
+        floatx4 d2[K::CC][K::TT];
+        if (valid) {
+            floatx4 d1[K::NTW][K::TT];
 #pragma unroll
-        for (int nt = 0; nt < K::NTW; ++nt)
+            for (int nt = 0; nt < K::NTW; ++nt) zero(d1[nt]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) d1[nt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int cc = 0; cc < K::CC; ++cc)
 #pragma unroll
-        for (int cc = 0; cc < K::CC; ++cc) {
-            floatx4 xa[4];           // B[k = q][n = m]: channel 16cc + 4q + s, pixel p0 + 4m + t
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const floatx4*>(xt + (size_t)(16 * cc + 4 * q + s) * P + 4 * m);
+                    for (int nt = 0; nt < K::NTW; ++nt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                        for (int t = 0; t < K::TT; ++t) mfma(d1[nt][t], w1r[nt][4 * cc + s], xn[cc][s][t]);
+            drain(d1);
+            if (it + 1 < iters && tile + per_it < ntiles) {         // the next tile's x, behind this tile's last use of xn
+                int bn, pn;
+                tile_of<C>(tile + per_it, P, bn, pn);
+#pragma unroll
+                for (int cc = 0; cc < K::CC; ++cc)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        xn[cc][s] = *reinterpret_cast<const VT*>(x + ((size_t)bn * C + 16 * cc + 4 * q + s) * P + pn + K::TT * m);
+            }
+            // BatchNorm + ReLU on the registers; d1[nt][t][i]: hidden j0 + 16nt + 4q + i, pixel p0 + TT m + t
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                for (int t = 0; t < K::TT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d1[nt][t][i] = fmaxf(fmaf(d1[nt][t][i], scv[nt][i], shv[nt][i]), 0.f);
+            if (h_tap) {                 // tests only: the hidden activation (its sign pattern is the ReLU branch the kernels take)
 #pragma unroll
                 for (int nt = 0; nt < K::NTW; ++nt)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) mfma(d1[nt][t], w1r[nt][4 * cc + s], xa[s][t]);
-        }
-        drain(d1);
-        // BatchNorm + ReLU on the registers; d1[nt][t][i]: hidden j0 + 16nt + 4q + i, pixel p0 + 4m + t
+                    for (int i = 0; i < 4; ++i) {
+                        VT v;
 #pragma unroll
-        for (int nt = 0; nt < K::NTW; ++nt)
+                        for (int t = 0; t < K::TT; ++t) v[t] = d1[nt][t][i];
+                        *reinterpret_cast<VT*>(h_tap + ((size_t)b * K::HID + j0 + 16 * nt + 4 * q + i) * P + p0 + K::TT * m) = v;
+                    }
+            }
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) d1[nt][t][i] = fmaxf(fmaf(d1[nt][t][i], scv[nt][i], shv[nt][i]), 0.f);
-        if (h_tap) {                 // tests only: the hidden activation (its sign pattern is the ReLU branch the kernels take)
+            for (int ct = 0; ct < K::CC; ++ct) zero(d2[ct]);
 #pragma unroll
             for (int nt = 0; nt < K::NTW; ++nt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<floatx4*>(h_tap + ((size_t)b * K::HID + j0 + 16 * nt + 4 * q + i) * P + p0 + 4 * m) =
-                        floatx4{d1[nt][0][i], d1[nt][1][i], d1[nt][2][i], d1[nt][3][i]};
+#pragma unroll
+                    for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) mfma(d2[ct][t], w2r[ct][nt][i], d1[nt][t][i]);
+            drain(d2);
         }
-        floatx4 d2[K::CC][4];
-#pragma unroll
-        for (int ct = 0; ct < K::CC; ++ct)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) d2[ct][t] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int nt = 0; nt < K::NTW; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
+        // d2[ct][t][i]: channel 16ct + 4q + i, pixel p0 + TT m + t
+        if constexpr (K::JS == 1) {
+            if (valid) {
 #pragma unroll
                 for (int ct = 0; ct < K::CC; ++ct)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) mfma(d2[ct][t], w2r[ct][nt][i], d1[nt][t][i]);
-        drain(d2);
-        // d2[ct][t][i]: channel 16ct + 4q + i, pixel p0 + 4m + t
-        if constexpr (K::JS == 1) {
+                    for (int i = 0; i < 4; ++i) {
+                        VT v;
+                        float a = 0.f, qq = 0.f;
 #pragma unroll
-            for (int ct = 0; ct < K::CC; ++ct)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const floatx4 v = {d2[ct][0][i], d2[ct][1][i], d2[ct][2][i], d2[ct][3][i]};
-                    *reinterpret_cast<floatx4*>(z2 + ((size_t)b * C + 16 * ct + 4 * q + i) * P + p0 + 4 * m) = v;
-                    s2a[4 * ct + i] += (v[0] + v[1]) + (v[2] + v[3]);
-                    s2q[4 * ct + i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                }
+                        for (int t = 0; t < K::TT; ++t) {
+                            v[t] = d2[ct][t][i];
+                            a += v[t];
+                            qq = fmaf(v[t], v[t], qq);
+                        }
+                        *reinterpret_cast<VT*>(z2 + ((size_t)b * C + 16 * ct + 4 * q + i) * P + p0 + K::TT * m) = v;
+                        s2a[4 * ct + i] += a;
+                        s2q[4 * ct + i] += qq;
+                    }
+            }
         } else {
+            if (valid) {
 #pragma unroll
-            for (int ct = 0; ct < K::CC; ++ct)
+                for (int ct = 0; ct < K::CC; ++ct)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<floatx4*>(redz + (size_t)(wave * C + 16 * ct + 4 * q + i) * TS + 4 * m) =
-                        floatx4{d2[ct][0][i], d2[ct][1][i], d2[ct][2][i], d2[ct][3][i]};
+                    for (int i = 0; i < 4; ++i) {
+                        VT v;
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) v[t] = d2[ct][t][i];
+                        *reinterpret_cast<VT*>(redz + (size_t)(wave * C + 16 * ct + 4 * q + i) * K::TS + K::TT * m) = v;
+                    }
+            }
             __syncthreads();
+            if (valid) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {                  // C * 16 float4 outputs over NTHR threads = 2 each
-                const int e = tid + k * K::NTHR, c = e >> 4, pg = e & 15;
-                floatx4 v = *reinterpret_cast<const floatx4*>(redz + (size_t)c * TS + 4 * pg);
+                for (int k = 0; k < 2; ++k) {                  // C * 16 vector outputs over the group's JS * 64 threads = 2 each
+                    const int e = gtid + k * K::JS * 64, c = e >> 4, pg = e & 15;
+                    const float* src = redz + (size_t)(grp * K::JS * C + c) * K::TS + K::TT * pg;
+                    VT v = *reinterpret_cast<const VT*>(src);
 #pragma unroll
-                for (int w = 1; w < K::JS; ++w) v += *reinterpret_cast<const floatx4*>(redz + (size_t)(w * C + c) * TS + 4 * pg);
-                *reinterpret_cast<floatx4*>(z2 + ((size_t)b * C + c) * P + p0 + 4 * pg) = v;
-                s2a[k] += (v[0] + v[1]) + (v[2] + v[3]);
-                s2q[k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    for (int w = 1; w < K::JS; ++w) v += *reinterpret_cast<const VT*>(src + (size_t)w * C * K::TS);
+                    *reinterpret_cast<VT*>(z2 + ((size_t)b * C + c) * P + p0 + K::TT * pg) = v;
+#pragma unroll
+                    for (int t = 0; t < K::TT; ++t) {
+                        s2a[k] += v[t];
+                        s2q[k] = fmaf(v[t], v[t], s2q[k]);
+                    }
+                }
             }
             __syncthreads();
         }
     }
     if (!part2) return;
-    float* row = part2 + (size_t)blockIdx.x * 2 * C;
+    // per tile group one row of (sum, sum of squares) per channel, then the groups in a fixed order
+    float* comb = reinterpret_cast<float*>(un);
+    __syncthreads();
     if constexpr (K::JS == 1) {
-        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4 * K::CC; ++k) {
             const float a = kmu::wave_reduce<kmu::OpSum, 16>(s2a[k]), qq = kmu::wave_reduce<kmu::OpSum, 16>(s2q[k]);
             if (m == 0) {
                 const int c = 16 * (k >> 2) + 4 * q + (k & 3);
-                redz[wave * 2 * C + c] = a;
-                redz[wave * 2 * C + C + c] = qq;
+                comb[grp * 2 * C + c] = a;
+                comb[grp * 2 * C + C + c] = qq;
             }
         }
-        __syncthreads();
-        for (int t = tid; t < 2 * C; t += K::NTHR) row[t] = ((redz[t] + redz[2 * C + t]) + redz[4 * C + t]) + redz[6 * C + t];
     } else {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float a = kmu::wave_reduce<kmu::OpSum, 16>(s2a[k]), qq = kmu::wave_reduce<kmu::OpSum, 16>(s2q[k]);
-            const int e = tid + k * K::NTHR;
-            if ((e & 15) == 0) row[e >> 4] = a, row[C + (e >> 4)] = qq;
+            const int e = gtid + k * K::JS * 64;
+            if ((e & 15) == 0) comb[grp * 2 * C + (e >> 4)] = a, comb[grp * 2 * C + C + (e >> 4)] = qq;
         }
+    }
+    __syncthreads();
+    float* row = part2 + (size_t)blockIdx.x * 2 * C;
+    for (int t = tid; t < 2 * C; t += K::NTHR) {
+        float s = comb[t];
+#pragma unroll
+        for (int g = 1; g < K::TG; ++g) s += comb[g * 2 * C + t];
+        row[t] = s;
     }
 }
 
@@ -487,16 +556,14 @@ __global__ __launch_bounds__(256) void ffn_apply_kernel(const float* __restrict_
                 const double unb = Ntot > 1.0 ? var * Ntot / (Ntot - 1.0) : var;
                 bn2.running_var[tid] = (1.f - bn2.momentum) * bn2.running_var[tid] + bn2.momentum * (float)unb;
             }
-            const float sc = bn2.gamma[tid] * rstd;
-            sc2[tid] = sc, sh2[tid] = bn2.beta[tid] - mean * sc;
+            bn_affine(bn2.gamma[tid], bn2.beta[tid], mean, rstd, sc2[tid], sh2[tid]);
             av[tid] = sigmoid_f(alpha[tid]);
         }
         if (blockIdx.x == 0 && tid == 0 && bn2.nbt) *bn2.nbt += 1;
     } else if (tid < C) {
         const float mean = bn2.running_mean[tid], rstd = 1.f / sqrtf(bn2.running_var[tid] + bn2.eps);
         if (blockIdx.x == 0) stats2[2 * tid] = mean, stats2[2 * tid + 1] = rstd;
-        const float sc = bn2.gamma[tid] * rstd;
-        sc2[tid] = sc, sh2[tid] = bn2.beta[tid] - mean * sc;
+        bn_affine(bn2.gamma[tid], bn2.beta[tid], mean, rstd, sc2[tid], sh2[tid]);
         av[tid] = sigmoid_f(alpha[tid]);
     }
     __syncthreads();
@@ -512,27 +579,27 @@ __global__ __launch_bounds__(256) void ffn_apply_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------ B1
-// per channel over all pixels: s0 = sum a g, s1 = sum a g z2hat, s2 = sum g (BN2(z2) - x)      -> q1 [G][3C]
+// per channel over all pixels: s0 = sum a g, s1 = sum a g z2hat, s2 = sum g (BN2(z2) - x)      -> q1 [G][3C]; 64-pixel tiles, 8 per iteration
 template <int C>
-__global__ __launch_bounds__(256) void ffn_bwd_red2_kernel(const float* __restrict__ g, const float* __restrict__ z2,
+__global__ __launch_bounds__(512) void ffn_bwd_red2_kernel(const float* __restrict__ g, const float* __restrict__ z2,
                                                            const float* __restrict__ x, const float* __restrict__ gamma2,
                                                            const float* __restrict__ beta2, const float* __restrict__ stats2,
-                                                           const float* __restrict__ alpha, float* __restrict__ q1, int P, int ntiles) {
+                                                           const float* __restrict__ alpha, float* __restrict__ q1, int P, int ntiles64) {
     constexpr int CC = C / 16;
-    __shared__ float comb[4 * 3 * C];
+    __shared__ float comb[8 * 3 * C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
     float mean[CC], rstd[CC], sc[CC], sh[CC], a[CC], s0[CC], s1[CC], s2[CC];
 #pragma unroll
     for (int ct = 0; ct < CC; ++ct) {
         const int c = 16 * ct + r;
         mean[ct] = stats2[2 * c], rstd[ct] = stats2[2 * c + 1];
-        sc[ct] = gamma2[c] * rstd[ct], sh[ct] = beta2[c] - mean[ct] * sc[ct];
+        bn_affine(gamma2[c], beta2[c], mean[ct], rstd[ct], sc[ct], sh[ct]);
         a[ct] = sigmoid_f(alpha[c]);
         s0[ct] = s1[ct] = s2[ct] = 0.f;
     }
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        int b, p0;
-        tile_of<C>(tile, P, b, p0);
+    const int tpp = P >> 6;
+    for (int tile = blockIdx.x * 8 + wave; tile < ntiles64; tile += gridDim.x * 8) {
+        const int b = tile / tpp, p0 = (tile - b * tpp) << 6;
 #pragma unroll
         for (int ct = 0; ct < CC; ++ct) {
             const size_t o = ((size_t)b * C + 16 * ct + r) * P + p0 + 4 * q;
@@ -563,21 +630,26 @@ __global__ __launch_bounds__(256) void ffn_bwd_red2_kernel(const float* __restri
     }
     __syncthreads();
     float* row = q1 + (size_t)blockIdx.x * 3 * C;
-    for (int t = threadIdx.x; t < 3 * C; t += 256) row[t] = ((comb[t] + comb[3 * C + t]) + comb[6 * C + t]) + comb[9 * C + t];
+    for (int t = threadIdx.x; t < 3 * C; t += 512) {
+        float s = comb[t];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s += comb[w * 3 * C + t];
+        row[t] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ B2 / B3
-// PASS 2: partial sums of BN1's backward + dW2 slabs.  PASS 3: dx + dW1 slabs.
+// PASS 2 (slice-major): partial sums of BN1's backward + dW2 slabs.  PASS 3 (tile-major): dx + dW1 slabs.
 template <int C, int PASS>
 struct BLds {
     using K = Cfg<C>;
     static constexpr int W_IN = PASS == 2 ? 3 * C : 2 * K::HID;                                   // width of the partial rows read
     static constexpr int RED_D = RowReduce<W_IN, K::NTHR>::SCRATCH + W_IN;                        // doubles (prologue)
-    static constexpr int T_ROWS = K::JS == 1 ? 4 * K::HID : K::HID;                               // dz1 tile(s), PASS 3
-    static constexpr int COMB_F = K::JS == 1 ? 4 * C * K::HID : 4;                                // cross-wave slab combine (JS == 1)
-    static constexpr int MAIN_F3 = T_ROWS * TS > COMB_F ? T_ROWS * TS : COMB_F;
-    static constexpr int MAIN_F2 = COMB_F > 4 * 2 * K::HID ? COMB_F : 4 * 2 * K::HID;
-    static constexpr int MAIN_F = PASS == 3 ? MAIN_F3 : MAIN_F2;
+    static constexpr int T_F = K::NW * 16 * K::TS;                                                // PASS 3: dz1 of 16 hidden channels per wave
+    static constexpr int COMB2_F = K::NW * C * K::SW > K::NW * 2 * K::SW ? K::NW * C * K::SW : K::NW * 2 * K::SW;   // PASS 2 epilogue
+    static constexpr int COMB3_F = K::TG > 1 ? K::TG * C * K::HID : 4;                             // PASS 3 epilogue: slabs of the tile groups
+    static constexpr int MAIN_F3 = T_F > COMB3_F ? T_F : COMB3_F;
+    static constexpr int MAIN_F = PASS == 3 ? MAIN_F3 : COMB2_F;
     static constexpr size_t UNION_B = (size_t)RED_D * 8 > (size_t)MAIN_F * 4 ? (size_t)RED_D * 8 : (size_t)MAIN_F * 4;
     static constexpr int WL_F = PASS == 3 ? K::HID * (C + 4) : 0;                                 // W1 [j][c], row stride C + 4
     static constexpr int CONST_F = 4 * C + 5 * K::HID;                                            // cst2 [C][4]; per hidden channel: 5 arrays
@@ -592,8 +664,8 @@ struct BArgs {
     float* cst2g;             // [C][4] {A, B, D, 1 - a}: written by PASS 2 (workgroup 0), read by PASS 3
     float *d_gamma2, *d_beta2, *d_alpha;    // PASS 2 (workgroup 0)
     float *d_gamma1, *d_beta1;              // PASS 3 (workgroup 0)
-    float* q2;                // PASS 2 out [G][2 HID]
-    float* slab;              // PASS 2: dW2 slabs [G][C][HID]; PASS 3: dW1 slabs [G][HID][C]
+    float* q2;                // PASS 2 out [R][JS][2][SW]
+    float* slab;              // PASS 2: dW2 slabs [R][C][HID]; PASS 3: dW1 slabs [G][HID][C]
     float* dx;                // PASS 3
     int P, ntiles;
     double Ntot;
@@ -603,18 +675,27 @@ template <int C, int PASS>
 __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_bwd_kernel(BArgs a) {
     using K = Cfg<C>;
     using L = BLds<C, PASS>;
+    typedef typename K::VT VT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     floatx4* cst2 = reinterpret_cast<floatx4*>(smem);                 // [C]
     float* hc = reinterpret_cast<float*>(smem) + 4 * C;               // [5][HID]: sc1, sh1, then (mean1, rstd1, -) or (k1, E, F)
     float* wl = hc + 5 * K::HID;                                      // PASS 3: W1 [HID][C + 4]
     char* un = smem + (size_t)(L::CONST_F + L::WL_F) * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
-    const int j0 = K::JS == 1 ? 0 : wave * 16 * K::NTW;
+    // PASS 2: slice = blockIdx % JS, the waves take different tiles; PASS 3: the waves of a tile group take its slices
+    int sm_slice = 0, r = 0, R = 0;
+    if constexpr (PASS == 2) slice_major<K::JS>(sm_slice, r, R);
+    const int slice = PASS == 2 ? sm_slice : wave % K::JS;
+    const int grp = PASS == 2 ? wave : wave / K::JS;                  // which of this workgroup's concurrent tiles
+    const int j0 = slice * K::SW;
     const int P = a.P;
 
     float w1r[K::NTW][4 * K::CC], w2r[K::NTW][4 * K::CC];
     load_w1r<C>(a.w1, j0, n, q, w1r);
     load_w2r<C>(a.w2, j0, n, q, w2r);
+    const int per_it = PASS == 2 ? R * K::NW : gridDim.x * K::TG;
+    const int unit0 = PASS == 2 ? r * K::NW + wave : blockIdx.x * K::TG + grp;
+    const int iters = (a.ntiles + per_it - 1) / per_it;
     if constexpr (PASS == 3) {
         for (int e = tid; e < K::HID * C; e += K::NTHR) {
             const int j = e / C, c = e - j * C;
@@ -653,11 +734,11 @@ __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_bwd_kernel(BArgs a) {
                 const float mean = a.stats1[2 * j], rstd = a.stats1[2 * j + 1];
                 float k1, sh;
                 bn_affine(a.gamma1[j], a.beta1[j], mean, rstd, k1, sh);
-                const float n0 = a.training ? (float)(tot[j] / a.Ntot) : 0.f, n1 = a.training ? (float)(tot[K::HID + j] / a.Ntot) : 0.f;
+                const float n0 = a.training ? (float)(tot[K::col(j, 0)] / a.Ntot) : 0.f, n1 = a.training ? (float)(tot[K::col(j, 1)] / a.Ntot) : 0.f;
                 // dz1 = k1 (dr - n0 - z1hat n1),  z1hat = (z1 - mean) rstd
                 hc[j] = k1, hc[K::HID + j] = sh;
                 hc[2 * K::HID + j] = k1, hc[3 * K::HID + j] = -k1 * n1 * rstd, hc[4 * K::HID + j] = k1 * (n1 * rstd * mean - n0);
-                if (blockIdx.x == 0) a.d_gamma1[j] = (float)tot[K::HID + j], a.d_beta1[j] = (float)tot[j];
+                if (blockIdx.x == 0) a.d_gamma1[j] = (float)tot[K::col(j, 1)], a.d_beta1[j] = (float)tot[K::col(j, 0)];
             }
         }
     }
@@ -670,200 +751,233 @@ __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_bwd_kernel(BArgs a) {
         sc1v[nt] = hc[j], sh1v[nt] = hc[K::HID + j], c2v[nt] = hc[2 * K::HID + j], c3v[nt] = hc[3 * K::HID + j];
         c4v[nt] = PASS == 3 ? hc[4 * K::HID + j] : 0.f;
     }
-    floatx4 cb[K::CC];                   // constants of channel 16ct + n (operand layout of the weight-gradient / output side)
-#pragma unroll
-    for (int ct = 0; ct < K::CC; ++ct) cb[ct] = cst2[16 * ct + n];
     __syncthreads();                     // the union region turns from reduction scratch into tile scratch
 
     float* T = reinterpret_cast<float*>(un);
     floatx4 acc[K::CC][K::NTW];          // PASS 2: dW2 tile (rows c = 16ct + 4q + i, column j); PASS 3: dW1 tile (rows j, column c = 16ct + n)
 #pragma unroll
-    for (int ct = 0; ct < K::CC; ++ct)
-#pragma unroll
-        for (int nt = 0; nt < K::NTW; ++nt) acc[ct][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < K::CC; ++ct) zero(acc[ct]);
     float t0[K::NTW], t1[K::NTW];
 #pragma unroll
     for (int nt = 0; nt < K::NTW; ++nt) t0[nt] = t1[nt] = 0.f;
-    const int poff = 4 * ((n >> 2) + 4 * (n & 3));
-    // PASS 3, JS > 1: this wave's share of the dx tile: channel tile ctw, pixel-tile pair (2th, 2th + 1)
-    const int ctw = K::JS == 1 ? 0 : wave % K::CC, th = K::JS == 1 ? 0 : wave / K::CC;
+    const int poff = K::TT * fperm(n);
+    // PASS 3: this wave's share of the dx tile of its group: DN pixel-tiles (own_t0 ..) of channel tile own_ct
+    constexpr int DN = K::JS == 1 ? K::TT : 2;
+    typedef typename Vec<DN>::type DV;
+    const int own_ct = K::JS == 1 ? 0 : slice % K::CC;
+    const int own_t0 = (K::JS == 1 || C == 64) ? 0 : 2 * (slice / K::CC);
+    const bool own = K::JS == 1 || C == 32 || slice < K::CC;          // C = 64: four waves (one per SIMD) carry the four channel tiles
+    float* Tg = T + (size_t)grp * K::JS * 16 * K::TS;                 // this tile group's 16 JS rows
 
-    for (int tile = blockIdx.x * K::TPI + (K::JS == 1 ? wave : 0); tile < a.ntiles; tile += gridDim.x * K::TPI) {
-        int b, p0;
-        tile_of<C>(tile, P, b, p0);
+    for (int it = 0; it < iters; ++it) {
+        const int tile = unit0 + it * per_it;
+        const bool valid = tile < a.ntiles;              // PASS 3: uniform over the tile group (barriers below are workgroup-wide)
+        if (PASS == 2 && !valid) continue;
+        int b = 0, p0 = 0;
+        if (valid) tile_of<C>(tile, P, b, p0);
         const size_t base = (size_t)b * C * P + p0;
-        floatx4 z1[K::NTW][4], dh[K::NTW][4];
-        fc1_dp<C>(a.x + base, P, w1r, z1, n, q);
-        dh_dp<C>(a.g + base, a.z2 + base, P, cst2, w2r, dh, n, q);
-        // z1 / dh [nt][t][i]: hidden j0 + 16nt + n, pixel p0 + 16i + 4q + t
+        floatx4 d[DN];
+        zero(d);
+        // LDS reads of per-channel constants and of W1 are loop invariant; hoisted out of the tile loop they would pin 64+ registers
+        // (and spill), so their offsets are made opaque once per tile
+        int cofs = 4 * q, wofs = 4 * q * (C + 4) + n;
+        asm volatile("" : "+v"(cofs), "+v"(wofs));
+        // phase A: z1 = W1 x and dh = W2^T dz2 of every hidden tile of this wave, from ONE layout-A load of x, g, z2
+        // (dz2 = A_c g + (B_c z2 + D_c)), then the element-wise step; hz[nt][t][i]: hidden j0 + 16nt + n, pixel p0 + 4TT i + TT q + t
+        floatx4 hz[K::NTW][K::TT];
+        if (valid) {
+            VT xa[K::CC][4], za[K::CC][4];
+            load_a<C>(a.x + base, P, xa, n, q);
 #pragma unroll
-        for (int nt = 0; nt < K::NTW; ++nt)
+            for (int cc = 0; cc < K::CC; ++cc) {
+                // one 16-channel chunk of g and z2 at a time: a "memory" fence keeps hipcc from issuing every load of the tile at
+                // once (it would, and then spills: all of x, g, z2 in two layouts do not fit beside the accumulators)
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int s = 0; s < 4; ++s) {
+                    const size_t o = base + (size_t)(16 * cc + 4 * q + s) * P + poff;
+                    const VT gv = *reinterpret_cast<const VT*>(a.g + o), zv = *reinterpret_cast<const VT*>(a.z2 + o);
+                    const floatx4 k = cst2[16 * cc + s + cofs];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float z = z1[nt][t][i], pre = fmaf(z, sc1v[nt], sh1v[nt]);
-                    const bool on = pre > 0.f;
-                    const float dr = on ? dh[nt][t][i] : 0.f;
-                    if constexpr (PASS == 2) {
-                        const float that = (z - c2v[nt]) * c3v[nt];
-                        t0[nt] += dr;
-                        t1[nt] = fmaf(dr, that, t1[nt]);
-                        z1[nt][t][i] = on ? pre : 0.f;                                   // h
-                    } else {
-                        z1[nt][t][i] = fmaf(c2v[nt], dr, fmaf(c3v[nt], z, c4v[nt]));     // dz1
+                    for (int t = 0; t < K::TT; ++t) za[cc][s][t] = fmaf(k[0], gv[t], fmaf(k[1], zv[t], k[2]));   // dz2
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt) {
+                floatx4 dh[K::TT];
+                fc1_dp<C>(xa, w1r[nt], hz[nt]);
+                fc1_dp<C>(za, w2r[nt], dh);
+#pragma unroll
+                for (int t = 0; t < K::TT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float z = hz[nt][t][i], pre = fmaf(z, sc1v[nt], sh1v[nt]);
+                        const bool on = pre > 0.f;
+                        const float dr = on ? dh[t][i] : 0.f;
+                        if constexpr (PASS == 2) {
+                            const float that = (z - c2v[nt]) * c3v[nt];
+                            t0[nt] += dr;
+                            t1[nt] = fmaf(dr, that, t1[nt]);
+                            hz[nt][t][i] = on ? pre : 0.f;                                   // h
+                        } else {
+                            hz[nt][t][i] = fmaf(c2v[nt], dr, fmaf(c3v[nt], z, c4v[nt]));     // dz1
+                        }
+                    }
+            }
+        }
+        // phase B: the weight-gradient product over this tile's pixels -- k-step (t, i) <-> pixels p0 + 4TT i + TT q + t, q = the MFMA's
+        // k; its other operand is dz2 (PASS 2) / x (PASS 3) in layout B -- and, PASS 3, dx through LDS, 16 hidden channels per round
+        asm volatile("" ::: "memory");           // phase B's loads stay below phase A's
+        VT vb[K::CC][4];
+        if (valid) {
+#pragma unroll
+            for (int ct = 0; ct < K::CC; ++ct) {
+                const size_t o = base + (size_t)(16 * ct + n) * P + K::TT * q;
+                if constexpr (PASS == 2) {
+                    const floatx4 cb = cst2[16 * ct + n];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const VT gv = *reinterpret_cast<const VT*>(a.g + o + 4 * K::TT * i), zv = *reinterpret_cast<const VT*>(a.z2 + o + 4 * K::TT * i);
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) vb[ct][i][t] = fmaf(cb[0], gv[t], fmaf(cb[1], zv[t], cb[2]));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vb[ct][i] = *reinterpret_cast<const VT*>(a.x + o + 4 * K::TT * i);
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < K::NTW; ++nt) {
+            if (valid) {
+#pragma unroll
+                for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+                    for (int t = 0; t < K::TT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if constexpr (PASS == 2) mfma(acc[ct][nt], vb[ct][i][t], hz[nt][t][i]);     // dW2[c][j] += dz2 h
+                            else mfma(acc[ct][nt], hz[nt][t][i], vb[ct][i][t]);                         // dW1[j][c] += dz1 x
+                        }
+            }
+            if constexpr (PASS == 3) {
+                // dz1 of these 16 hidden channels -> T[slice rows][pixel]: its transpose-through-LDS for dx[pixel][c] += dz1[pixel][j] W1[j][c]
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        VT v;
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) v[t] = hz[nt][t][i];
+                        *reinterpret_cast<VT*>(Tg + (size_t)(slice * 16 + n) * K::TS + 4 * K::TT * i + K::TT * q) = v;
                     }
                 }
-        // weight-gradient product over this tile's pixels: k-step (t, i) <-> pixels p0 + 16i + 4q + t, q = the MFMA's k
-#pragma unroll
-        for (int ct = 0; ct < K::CC; ++ct) {
-            const size_t o = base + (size_t)(16 * ct + n) * P + 4 * q;
-            floatx4 v[4];
-            if constexpr (PASS == 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const floatx4 gv = *reinterpret_cast<const floatx4*>(a.g + o + 16 * i), zv = *reinterpret_cast<const floatx4*>(a.z2 + o + 16 * i);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[i][t] = fmaf(cb[ct][0], gv[t], fmaf(cb[ct][1], zv[t], cb[ct][2]));   // dz2
+                if constexpr (K::JS == 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                } else {
+                    __syncthreads();
                 }
+                if (valid && own) {
 #pragma unroll
-                for (int nt = 0; nt < K::NTW; ++nt)
+                    for (int sl = 0; sl < K::JS; ++sl) {
+                        if (sl & 1) asm volatile("" ::: "memory");           // at most two slices' operand reads in flight
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                        for (int s = 0; s < 4; ++s) {
+                            const int row = sl * 16 + 4 * q + s;                                  // hidden channel sl*SW + 16nt + 4q + s
+                            const DV av = *reinterpret_cast<const DV*>(Tg + (size_t)row * K::TS + poff + own_t0);
+                            const float bv = wl[(sl * K::SW + 16 * nt + s) * (C + 4) + 16 * own_ct + wofs];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) mfma(acc[ct][nt], v[i][t], z1[nt][t][i]);     // dW2[c][j] += dz2 h
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const floatx4*>(a.x + o + 16 * i);
-#pragma unroll
-                for (int nt = 0; nt < K::NTW; ++nt)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) mfma(acc[ct][nt], z1[nt][t][i], v[i][t]);     // dW1[j][c] += dz1 x
+                            for (int k = 0; k < DN; ++k) mfma(d[k], av[k], bv);
+                        }
+                    }
+                }
+                if constexpr (K::JS == 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    __syncthreads();             // T is rewritten by the next round
+                }
             }
         }
         if constexpr (PASS == 3) {
-            // dz1 -> T[j][pixel]: its transpose-through-LDS for dx[pixel][c] = sum_j dz1[pixel][j] W1[j][c]
-            float* Tw = T + (K::JS == 1 ? (size_t)wave * K::HID * TS : 0);
-#pragma unroll
-            for (int nt = 0; nt < K::NTW; ++nt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<floatx4*>(Tw + (size_t)(j0 + 16 * nt + n) * TS + 16 * i + 4 * q) =
-                        floatx4{z1[nt][0][i], z1[nt][1][i], z1[nt][2][i], z1[nt][3][i]};
-            if constexpr (K::JS == 1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            } else {
-                __syncthreads();
-            }
-            if constexpr (K::JS == 1) {
-                floatx4 d[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) d[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-                for (int jt = 0; jt < K::HID / 16; ++jt)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int j = 16 * jt + 4 * q + s;
-                        const floatx4 av = *reinterpret_cast<const floatx4*>(Tw + (size_t)j * TS + poff);
-                        const float bv = wl[j * (C + 4) + n];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) mfma(d[t], av[t], bv);
-                    }
+            if (valid && own) {
                 drain(d);
-                // d[t][i]: pixel p0 + 16i + 4q + t, channel n
-                const size_t o = base + (size_t)n * P + 4 * q;
+                // d[k][i]: pixel p0 + 4TT i + TT q + own_t0 + k, channel 16 own_ct + n
+                const size_t o = base + (size_t)(16 * own_ct + n) * P + K::TT * q + own_t0;
+                const float oma = cst2[16 * own_ct + n][3];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const floatx4 gv = *reinterpret_cast<const floatx4*>(a.g + o + 16 * i);
-                    floatx4 v;
+                    const DV gv = *reinterpret_cast<const DV*>(a.g + o + 4 * K::TT * i);
+                    DV v;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = fmaf(cb[0][3], gv[t], d[t][i]);
-                    *reinterpret_cast<floatx4*>(a.dx + o + 16 * i) = v;
+                    for (int k = 0; k < DN; ++k) v[k] = fmaf(oma, gv[k], d[k][i]);
+                    *reinterpret_cast<DV*>(a.dx + o + 4 * K::TT * i) = v;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                floatx4 d[2];
-                d[0] = d[1] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-                for (int jt = 0; jt < K::HID / 16; ++jt)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int j = 16 * jt + 4 * q + s;
-                        const floatx2 av = *reinterpret_cast<const floatx2*>(T + (size_t)j * TS + poff + 2 * th);
-                        const float bv = wl[j * (C + 4) + 16 * ctw + n];
-                        mfma(d[0], av[0], bv);
-                        mfma(d[1], av[1], bv);
-                    }
-                drain(d);
-                // d[tt][i]: pixel p0 + 16i + 4q + 2th + tt, channel 16ctw + n
-                const size_t o = base + (size_t)(16 * ctw + n) * P + 4 * q + 2 * th;
-                const float oma = cst2[16 * ctw + n][3];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const floatx2 gv = *reinterpret_cast<const floatx2*>(a.g + o + 16 * i);
-                    floatx2 v = {fmaf(oma, gv[0], d[0][i]), fmaf(oma, gv[1], d[1][i])};
-                    *reinterpret_cast<floatx2*>(a.dx + o + 16 * i) = v;
-                }
-                __syncthreads();             // T is rewritten by the next tile
             }
         }
     }
 
     // ---- epilogue: partial row of BN1's backward sums (PASS 2) and this workgroup's weight-gradient slab
+#pragma unroll
+    for (int ct = 0; ct < K::CC; ++ct) drain(acc[ct]);
+    __syncthreads();
     if constexpr (PASS == 2) {
+        // the 8 waves hold sums over different tiles of the SAME slice: add them in a fixed order
 #pragma unroll
         for (int nt = 0; nt < K::NTW; ++nt) {
             t0[nt] += __shfl_xor(t0[nt], 16), t0[nt] += __shfl_xor(t0[nt], 32);
             t1[nt] += __shfl_xor(t1[nt], 16), t1[nt] += __shfl_xor(t1[nt], 32);
+            if (q == 0) T[wave * 2 * K::SW + 16 * nt + n] = t0[nt], T[wave * 2 * K::SW + K::SW + 16 * nt + n] = t1[nt];
         }
-        float* row = a.q2 + (size_t)blockIdx.x * 2 * K::HID;
-        if constexpr (K::JS == 1) {
-            __syncthreads();
-            if (q == 0) {
+        __syncthreads();
+        float* row = a.q2 + ((size_t)r * K::JS + slice) * 2 * K::SW;
+        for (int t = tid; t < 2 * K::SW; t += K::NTHR) {
+            float s = T[t];
 #pragma unroll
-                for (int nt = 0; nt < K::NTW; ++nt) {
-                    T[wave * 2 * K::HID + 16 * nt + n] = t0[nt];
-                    T[wave * 2 * K::HID + K::HID + 16 * nt + n] = t1[nt];
-                }
-            }
-            __syncthreads();
-            for (int t = tid; t < 2 * K::HID; t += K::NTHR) row[t] = ((T[t] + T[2 * K::HID + t]) + T[4 * K::HID + t]) + T[6 * K::HID + t];
-        } else if (q == 0) {
-#pragma unroll
-            for (int nt = 0; nt < K::NTW; ++nt) row[j0 + 16 * nt + n] = t0[nt], row[K::HID + j0 + 16 * nt + n] = t1[nt];
+            for (int w = 1; w < K::NW; ++w) s += T[w * 2 * K::SW + t];
+            row[t] = s;
         }
-    }
-    drain(acc);
-    float* slab = a.slab + (size_t)blockIdx.x * C * K::HID;
-    if constexpr (K::JS == 1) {                    // the four waves hold partial sums of the SAME tile: add them in a fixed order
         __syncthreads();
 #pragma unroll
         for (int ct = 0; ct < K::CC; ++ct)
 #pragma unroll
             for (int nt = 0; nt < K::NTW; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = PASS == 2 ? (16 * ct + 4 * q + i) * K::HID + 16 * nt + n : (16 * nt + 4 * q + i) * C + 16 * ct + n;
-                    T[(size_t)wave * C * K::HID + e] = acc[ct][nt][i];
-                }
+                for (int i = 0; i < 4; ++i) T[(size_t)wave * C * K::SW + (16 * ct + 4 * q + i) * K::SW + 16 * nt + n] = acc[ct][nt][i];
         __syncthreads();
-        for (int e = tid; e < C * K::HID; e += K::NTHR)
-            slab[e] = ((T[e] + T[C * K::HID + e]) + T[2 * C * K::HID + e]) + T[3 * C * K::HID + e];
+        float* slab = a.slab + (size_t)r * C * K::HID;
+        for (int e = tid; e < C * K::SW; e += K::NTHR) {
+            float s = T[e];
+#pragma unroll
+            for (int w = 1; w < K::NW; ++w) s += T[(size_t)w * C * K::SW + e];
+            slab[(e / K::SW) * K::HID + j0 + (e % K::SW)] = s;
+        }
     } else {
+        float* slab = a.slab + (size_t)blockIdx.x * C * K::HID;
+        if constexpr (K::TG > 1) {       // the tile groups hold sums of different tiles for the same (j, c): fixed-order add
 #pragma unroll
-        for (int ct = 0; ct < K::CC; ++ct)
+            for (int ct = 0; ct < K::CC; ++ct)
 #pragma unroll
-            for (int nt = 0; nt < K::NTW; ++nt)
+                for (int nt = 0; nt < K::NTW; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = PASS == 2 ? (16 * ct + 4 * q + i) * K::HID + j0 + 16 * nt + n : (j0 + 16 * nt + 4 * q + i) * C + 16 * ct + n;
-                    slab[e] = acc[ct][nt][i];
-                }
+                    for (int i = 0; i < 4; ++i) T[(size_t)grp * C * K::HID + (j0 + 16 * nt + 4 * q + i) * C + 16 * ct + n] = acc[ct][nt][i];
+            __syncthreads();
+            for (int e = tid; e < C * K::HID; e += K::NTHR) {
+                float s = T[e];
+#pragma unroll
+                for (int g2 = 1; g2 < K::TG; ++g2) s += T[(size_t)g2 * C * K::HID + e];
+                slab[e] = s;
+            }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+                for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) slab[(j0 + 16 * nt + 4 * q + i) * C + 16 * ct + n] = acc[ct][nt][i];
+        }
     }
 }
 
@@ -874,11 +988,16 @@ inline int rows_for(int iters, int gmax) {      // largest workgroup count <= gm
     return (iters + per - 1) / per;
 }
 template <int C>
-int ffn_rows(int B, int P) {
-    const int ntiles = B * (P / 64);
-    return rows_for((ntiles + Cfg<C>::TPI - 1) / Cfg<C>::TPI, Cfg<C>::GMAX);
-}
-inline int red2_rows(int B, int P) { return rows_for((B * (P / 64) + 3) / 4, 256); }
+struct Plan {
+    int ntiles, G, R;      // tiles; tile-major workgroups (= rows of part2 / slab_w1); slice-major rows (part1, q2, slab_w2), grid = JS * R
+    Plan(int B, int P) {
+        using K = Cfg<C>;
+        ntiles = B * (P / K::TP);
+        G = rows_for((ntiles + K::TG - 1) / K::TG, KMU_FFN_GMAX);
+        R = rows_for((ntiles + K::NW - 1) / K::NW, KMU_FFN_GMAX / K::JS);
+    }
+};
+inline int red2_rows(int B, int P) { return rows_for((B * (P / 64) + 7) / 8, 256); }
 inline int apply_blocks(long total4) {
     long g = (total4 + 256 * 8 - 1) / (256 * 8);
     return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
@@ -893,26 +1012,26 @@ struct FwdPtrs {
 template <int C>
 int ffn_fwd_t(const FwdPtrs& p, int training, float* ws, int B, int P, int stage, hipStream_t st) {
     using K = Cfg<C>;
-    const int ntiles = B * (P / 64), G = ffn_rows<C>(B, P);
+    const Plan<C> pl(B, P);
     float* part1 = ws;
-    float* part2 = ws + (size_t)G * 2 * K::HID;
+    float* part2 = ws + (size_t)pl.R * 2 * K::HID;
     const double Ntot = (double)B * (double)P;
     int rc = 0;
     if ((stage < 0 || stage == 0) && training) {
-        hipLaunchKernelGGL((ffn_stats1_kernel<C>), dim3(G), dim3(K::NTHR), 0, st, p.x, p.w1, part1, P, ntiles);
+        hipLaunchKernelGGL((ffn_stats1_kernel<C>), dim3(K::JS * pl.R), dim3(K::NTHR), 0, st, p.x, p.w1, part1, P, pl.ntiles);
         if ((rc = kmu::launch_status("ffn_fused_fwd stats"))) return rc;
     }
     if (stage < 0 || stage == 1) {
         const size_t lds = F2Lds<C>::BYTES;
         KMU_MAX_LDS((ffn_fwd_main_kernel<C>), lds);
-        hipLaunchKernelGGL((ffn_fwd_main_kernel<C>), dim3(G), dim3(K::NTHR), lds, st, p.x, p.w1, p.w2, p.bn1, part1, G, training, p.stats1,
-                           p.z2, training ? part2 : (float*)nullptr, p.h_tap, P, ntiles, Ntot);
+        hipLaunchKernelGGL((ffn_fwd_main_kernel<C>), dim3(pl.G), dim3(K::NTHR), lds, st, p.x, p.w1, p.w2, p.bn1, part1, pl.R, training,
+                           p.stats1, p.z2, training ? part2 : (float*)nullptr, p.h_tap, P, pl.ntiles, Ntot);
         if ((rc = kmu::launch_status("ffn_fused_fwd main"))) return rc;
     }
     if (stage < 0 || stage == 2) {
         const long total4 = (long)B * C * P / 4;
-        hipLaunchKernelGGL((ffn_apply_kernel<C>), dim3(apply_blocks(total4)), dim3(256), 0, st, p.z2, p.x, p.bn2, p.alpha, part2, G, training,
-                           p.stats2, p.out, P / 4, total4, Ntot);
+        hipLaunchKernelGGL((ffn_apply_kernel<C>), dim3(apply_blocks(total4)), dim3(256), 0, st, p.z2, p.x, p.bn2, p.alpha, part2, pl.G,
+                           training, p.stats2, p.out, P / 4, total4, Ntot);
         rc = kmu::launch_status("ffn_fused_fwd apply");
     }
     return rc;
@@ -921,28 +1040,30 @@ int ffn_fwd_t(const FwdPtrs& p, int training, float* ws, int B, int P, int stage
 template <int C>
 int ffn_bwd_t(BArgs a, const float* beta2, float* slab_w1, float* slab_w2, float* ws, int B, int P, int stage, hipStream_t st) {
     using K = Cfg<C>;
-    const int ntiles = B * (P / 64), G = ffn_rows<C>(B, P), G1 = red2_rows(B, P);
+    const Plan<C> pl(B, P);
+    const int G1 = red2_rows(B, P);
     float* q1 = ws;
     float* q2 = q1 + (size_t)G1 * 3 * C;
-    float* cst2g = q2 + (size_t)G * 2 * K::HID;
-    a.P = P, a.ntiles = ntiles, a.Ntot = (double)B * (double)P, a.cst2g = cst2g, a.q2 = q2;
+    float* cst2g = q2 + (size_t)pl.R * 2 * K::HID;
+    a.P = P, a.ntiles = pl.ntiles, a.Ntot = (double)B * (double)P, a.cst2g = cst2g, a.q2 = q2;
     int rc = 0;
     if (stage < 0 || stage == 0) {
-        hipLaunchKernelGGL((ffn_bwd_red2_kernel<C>), dim3(G1), dim3(256), 0, st, a.g, a.z2, a.x, a.gamma2, beta2, a.stats2, a.alpha, q1, P, ntiles);
+        hipLaunchKernelGGL((ffn_bwd_red2_kernel<C>), dim3(G1), dim3(512), 0, st, a.g, a.z2, a.x, a.gamma2, beta2, a.stats2, a.alpha, q1, P,
+                           B * (P / 64));
         if ((rc = kmu::launch_status("ffn_fused_bwd reduce"))) return rc;
     }
     if (stage < 0 || stage == 1) {
         a.part_in = q1, a.Gin = G1, a.slab = slab_w2;
         const size_t lds = BLds<C, 2>::BYTES;
         KMU_MAX_LDS((ffn_bwd_kernel<C, 2>), lds);
-        hipLaunchKernelGGL((ffn_bwd_kernel<C, 2>), dim3(G), dim3(K::NTHR), lds, st, a);
+        hipLaunchKernelGGL((ffn_bwd_kernel<C, 2>), dim3(K::JS * pl.R), dim3(K::NTHR), lds, st, a);
         if ((rc = kmu::launch_status("ffn_fused_bwd mid"))) return rc;
     }
     if (stage < 0 || stage == 2) {
-        a.part_in = q2, a.Gin = G, a.slab = slab_w1;
+        a.part_in = q2, a.Gin = pl.R, a.slab = slab_w1;
         const size_t lds = BLds<C, 3>::BYTES;
         KMU_MAX_LDS((ffn_bwd_kernel<C, 3>), lds);
-        hipLaunchKernelGGL((ffn_bwd_kernel<C, 3>), dim3(G), dim3(K::NTHR), lds, st, a);
+        hipLaunchKernelGGL((ffn_bwd_kernel<C, 3>), dim3(pl.G), dim3(K::NTHR), lds, st, a);
         rc = kmu::launch_status("ffn_fused_bwd input");
     }
     return rc;
@@ -950,24 +1071,39 @@ int ffn_bwd_t(BArgs a, const float* beta2, float* slab_w1, float* slab_w2, float
 
 inline bool ffn_ok(int C, int hid, int P) { return (C == 16 || C == 32 || C == 64) && hid == 4 * C && P > 0 && P % 64 == 0; }
 
+template <int C>
+size_t fwd_ws_floats(int B, int P) {
+    const Plan<C> pl(B, P);
+    return (size_t)pl.R * 2 * Cfg<C>::HID + (size_t)pl.G * 2 * C;
+}
+template <int C>
+size_t bwd_ws_floats(int B, int P) {
+    const Plan<C> pl(B, P);
+    return (size_t)red2_rows(B, P) * 3 * C + (size_t)pl.R * 2 * Cfg<C>::HID + 4 * C;
+}
+
 }  // namespace
 
 extern "C" int kmu_ffn_fused_supported(int C, int hid, int P) { return ffn_ok(C, hid, P) ? 1 : 0; }
 
-extern "C" int kmu_ffn_fused_rows(int B, int C, int P) {
-    if (B <= 0 || !ffn_ok(C, 4 * C, P)) return 0;
-    return C == 16 ? ffn_rows<16>(B, P) : (C == 32 ? ffn_rows<32>(B, P) : ffn_rows<64>(B, P));
+// rows of the weight-gradient slabs: which = 1 -> slab_w1 [rows][4C][C], which = 2 -> slab_w2 [rows][C][4C]
+extern "C" int kmu_ffn_fused_rows(int B, int C, int P, int which) {
+    if (B <= 0 || !ffn_ok(C, 4 * C, P) || (which != 1 && which != 2)) return 0;
+    switch (C) {
+        case 16: return which == 1 ? Plan<16>(B, P).G : Plan<16>(B, P).R;
+        case 32: return which == 1 ? Plan<32>(B, P).G : Plan<32>(B, P).R;
+        default: return which == 1 ? Plan<64>(B, P).G : Plan<64>(B, P).R;
+    }
 }
 
 extern "C" size_t kmu_ffn_fused_fwd_ws_bytes(int B, int C, int P) {
-    const int G = kmu_ffn_fused_rows(B, C, P);
-    return (size_t)G * (2 * 4 * C + 2 * C) * sizeof(float);
+    if (B <= 0 || !ffn_ok(C, 4 * C, P)) return 0;
+    return sizeof(float) * (C == 16 ? fwd_ws_floats<16>(B, P) : (C == 32 ? fwd_ws_floats<32>(B, P) : fwd_ws_floats<64>(B, P)));
 }
 
 extern "C" size_t kmu_ffn_fused_bwd_ws_bytes(int B, int C, int P) {
-    const int G = kmu_ffn_fused_rows(B, C, P);
-    if (!G) return 0;
-    return ((size_t)red2_rows(B, P) * 3 * C + (size_t)G * 2 * 4 * C + 4 * C) * sizeof(float);
+    if (B <= 0 || !ffn_ok(C, 4 * C, P)) return 0;
+    return sizeof(float) * (C == 16 ? bwd_ws_floats<16>(B, P) : (C == 32 ? bwd_ws_floats<32>(B, P) : bwd_ws_floats<64>(B, P)));
 }
 
 extern "C" int kmu_ffn_fused_fwd(const float* x, const float* w1, const float* gamma1, const float* beta1, float* running_mean1,

@@ -1496,10 +1496,10 @@ class FfnFusedFn(torch.autograd.Function):
         g = _f32c(g, "grad")
         B, C, H, W = x.shape
         P, hid, dev = H * W, w1.shape[0], x.device
-        rows = lib.kmu_ffn_fused_rows(B, C, P)
+        rows1, rows2 = lib.kmu_ffn_fused_rows(B, C, P, 1), lib.kmu_ffn_fused_rows(B, C, P, 2)
         mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         dx, dg1, db1, dg2, db2, da = torch.empty_like(x), mk(hid), mk(hid), mk(C), mk(C), mk(C)
-        slab1, slab2 = mk(rows, hid * C), mk(rows, C * hid)
+        slab1, slab2 = mk(rows1, hid * C), mk(rows2, C * hid)
         nbytes = lib.kmu_ffn_fused_bwd_ws_bytes(B, C, P)
         ws = mk(nbytes // 4)
         st = _stream()
