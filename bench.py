@@ -40,6 +40,11 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
 
 
+# what is stored and what is multiplied: every tensor in HBM is fp32 and every accumulation is fp32; the K x K contractions (K1, K2
+# forward / pass A, the plain 3x3 / 5x5 / 7x7 convs) form their products on the bf16 matrix core from operands split into two bf16
+# (hi*hi + hi*lo + lo*hi, ~16 significant bits); the 1x1 contractions and K2's pass B use the exact-fp32 MFMA
+DTYPE = "f32 storage + accumulate; split-bf16 (bf16x3) products in the KxK contractions"
+
 RIDGE = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # FLOP/B at which fp32 MFMA and HBM roofs cross (19.7)
 
 
@@ -172,7 +177,7 @@ def cpu_baseline(T, H, B=8, steps=2, loss="hybrid"):
         if i:
             times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    return {"value": B * T / t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": B * T / t, "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": "oracle KM_UNetV3 train step (fwd+%s loss+bwd+AdamW) at B=%d,T=%d,%dx%d fp32, median of %d steps after 1 warm-up, %.2f s/step"
                       % (loss, B, T, H, H, steps, t)}
 
@@ -267,12 +272,13 @@ def main():
         ms = dt / args.steps * 1e3
         out = {"metric": "train frames/sec (BxT) KM-UNetV3_SH 128x128 T=10", "value": world * B * T / (dt / args.steps),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                "config": {"workload": "KM_UNetV3_SH(num_classes=%d) train step (fwd + %s loss + bwd + grad all-reduce + AdamW), "
                                       "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, args.loss, B, T, H, H),
                           "global_batch": world * B, "frames_per_sample": T, "parallelism": "dp%d" % world},
                "loss_first": loss_ref, "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay",
-               "collective": ("%s all-reduce of %d floats per step" % (backend, eager.dp.bucket.numel())) if eager.dp.collective else "none (1 rank)"}
+               "collective": ("%s all-reduce (average) of %d floats per step over %d rank(s), world %d" % (
+                   backend, eager.dp.bucket.numel(), dist.get_world_size(), world)) if eager.dp.collective else "none (1 rank)"}
 
     # ---- roofline leg: extra instrumented steps, HIP events around every C-ABI launch ----------
     # (every rank runs them -- a step contains the gradient all-reduce -- only rank 0 records and reports)
@@ -303,6 +309,13 @@ def main():
                      "algorithmic_bytes": byts, "hbm_GBps_on_algorithmic_bytes": d["GB/s"]})
         out["roofline"] = {k: (float("%.5g" % v) if isinstance(v, float) else v) for k, v in roof.items()}
         out["hip_kernels_ms_per_step"] = round(sum(v["ms_per_step"] for v in table.values()), 4)
+        # BASELINE.json north_star: "the KANConv2D+SSM fused forward at B=8": K1 + K2 forward launches of one step, HIP-event time of
+        # the instrumented steps, against SURVEY.md 8(d)'s algorithmic 24.2 MB per sample (fp32) at 128x128
+        ns = [v for k, v in table.items() if k.startswith(("kan_conv2d_fwd", "hsmssd_fwd"))]
+        ns_us = 1e3 * sum(v["ms_per_step"] for v in ns)
+        ns_bytes = 24.2e6 * B * (H / 128.0) ** 2
+        out["north_star"] = {"k1k2_fwd_us": round(ns_us, 1), "launches": int(round(sum(v["launches_per_step"] for v in ns))),
+                             "algorithmic_bytes": ns_bytes, "hbm_frac": float("%.4g" % (ns_bytes / (ns_us * 1e-6) / (PEAK_HBM_GBS * 1e9)))}
         kernels = {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
                    sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}
         try:

@@ -698,20 +698,11 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
     float* delta = dhp + (size_t)B * C * NS;
     unsigned short* wpk = reinterpret_cast<unsigned short*>(delta + (size_t)B * NS);
     const size_t la = lds_passA_x3<C>(), lg = (size_t)7 * C * GN * sizeof(float);
-    // Pass B: the exact-fp32 kernel.  The matrix-core pass B (hsm_bwd_passB_x3, csrc/hsmssd_x3.inc) is experimental: see its header.
-#ifdef KMU_EXPERIMENTAL_PASSB_X3
-    unsigned short* wpkT = wpk + pack_x3_elems(C);
-    static const bool pb_x3 = getenv("KMU_K2_PASSB") && !strcmp(getenv("KMU_K2_PASSB"), "x3");
-#else
-    const bool pb_x3 = false;
-#endif
-    const bool split_dx = !pb_x3 && passB_split(C, Hs) == 2;      // fp32 pass B at C = 64: two workgroups per tile add into dx
+    // Pass B: the exact-fp32 kernel (hsmssd_bwd.inc).
+    const bool split_dx = passB_split(C, Hs) == 2;      // fp32 pass B at C = 64: two workgroups per tile add into dx
     int rc = 0;
     if (stages & 1) {
         hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48, NG), dim3(256), 0, st, w_bcdt, w_dw, wpk);
-#ifdef KMU_EXPERIMENTAL_PASSB_X3
-        hipLaunchKernelGGL(hsm_packT_x3_kernel<C>, dim3(48), dim3(256), 0, st, w_bcdt, w_dw, wpkT);
-#endif
         rc = kmu::launch_status("hsmssd_bwd pack");
         if (rc) return rc;
         KMU_MAX_LDS(hsm_bwd_passA_x3<C>, la);
@@ -726,17 +717,6 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
         if (rc) return rc;
     }
     if (stages & 4) {
-#ifdef KMU_EXPERIMENTAL_PASSB_X3
-        if (pb_x3) {
-            int txB;
-            const int TB = tilesB_x3<C>(Hs, &txB);
-            const size_t lb = XB<C>::LDS;
-            KMU_MAX_LDS(hsm_bwd_passB_x3<C>, lb);
-            hipLaunchKernelGGL(hsm_bwd_passB_x3<C>, dim3(TB, B), dim3(XB<C>::NW * 64), lb, st, x, dy, w_bcdt, w_dw, (const bf16x8*)wpk,
-                               (const bf16x8*)wpkT, state, dhp, delta, dx, p_bcdt, p_dw, Hs, txB);
-            rc = kmu::launch_status("hsmssd_bwd passB (bf16x3)");
-        } else
-#endif
         {
             int txF;
             const int TBF = tilesB_for(C, Hs, &txF);
@@ -891,14 +871,10 @@ extern "C" int kmu_hsmssd_bwd_partials(int B, int C, int Hs) {
 extern "C" size_t kmu_hsmssd_bwd_ws_bytes_x3(int B, int C, int N, int Hs) {
     int tx;
     const int TA = C == 16 ? tiles_x3<16>(Hs, &tx) : (C == 32 ? tiles_x3<32>(Hs, &tx) : tiles_x3<64>(Hs, &tx));
-    return ((size_t)B * TA * C * N + (size_t)B * C * N + (size_t)B * N) * sizeof(float) + (pack_x3_elems(C) + packT_x3_elems(C)) * 2;
+    return ((size_t)B * TA * C * N + (size_t)B * C * N + (size_t)B * N) * sizeof(float) + pack_x3_elems(C) * 2;
 }
 extern "C" int kmu_hsmssd_bwd_partials_x3(int B, int C, int Hs) {
     int tx;
-#ifdef KMU_EXPERIMENTAL_PASSB_X3
-    static const bool pb_x3 = getenv("KMU_K2_PASSB") && !strcmp(getenv("KMU_K2_PASSB"), "x3");
-    if (pb_x3) return B * (C == 16 ? tilesB_x3<16>(Hs, &tx) : (C == 32 ? tilesB_x3<32>(Hs, &tx) : tilesB_x3<64>(Hs, &tx)));
-#endif
     return B * tilesB_for(C, Hs, &tx);       // pass B runs on the exact-fp32 kernel: its tiling
 }
 

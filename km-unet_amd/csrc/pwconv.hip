@@ -34,6 +34,8 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
     return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.39894228040143268f * __expf(-0.5f * v * v);
 }
 
+constexpr int KT_MAX = 256;      // contraction channels per LDS weight tile
+
 __host__ __device__ inline int lds_stride(int nt) { return (16 * nt) % 32 == 16 ? 16 * nt : 16 * nt + 16; }
 
 // ---------------------------------------------------------------------------------------- fwd / bwd_input
@@ -59,57 +61,66 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
     // this wave's first x chunk is requested BEFORE the weights are staged: the two round trips (x from HBM, W from L2 + the
     // barrier) then overlap instead of queueing behind each other in every (short-lived) workgroup
     const float* xb = x + ((size_t)b * G + g) * K * P + p0 + 4 * ((m >> 2) + 4 * (m & 3));
+    const bool live = p0 < P;           // a wave past the end of the sample still takes part in the barriers below
     floatx4 xv[4], xn[4];
-    if (p0 < P) {
+    if (live) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) xv[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(4 * q + s) * P);
     }
-    // stage W[n0 .. n0+16NT) x [0, K) -> wl[k][n]
-    if (w_sk == 1) {
-        for (int e = tid; e < 16 * NT * K; e += 256) {
-            const int n = e / K, k = e - n * K;
-            wl[k * S + n] = w[(long)(nl0 + n) * w_sn + k];
-        }
-    } else {
-        for (int e = tid; e < 16 * NT * K; e += 256) {
-            const int k = e / (16 * NT), n = e - k * 16 * NT;
-            wl[k * S + n] = w[(long)(nl0 + n) * w_sn + (long)k * w_sk];
-        }
-    }
-    __syncthreads();
-    if (p0 >= P) return;
-
     floatx4 acc[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[nt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    // the contraction runs in tiles of <= KT_MAX channels: the weight tile W[n0 .. n0+16NT) x [k0, k0 + kt) sits in LDS as wl[k][n]
+    // (K > KT_MAX: DAGEM's deformable-conv contraction over Cin * 9 = 576 sampled columns, DAGEM_md.py:98-101)
     const int nchunk = K / 16;
-    for (int c = 0; c < nchunk; ++c) {
-        if (c + 1 < nchunk) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) xn[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(16 * (c + 1) + 4 * q + s) * P);
+    for (int k0 = 0; k0 < K; k0 += KT_MAX) {
+        const int kt = min(KT_MAX, K - k0);
+        if (k0) __syncthreads();        // every wave is done with the previous weight tile
+        if (w_sk == 1) {
+            for (int e = tid; e < 16 * NT * kt; e += 256) {
+                const int n = e / kt, k = e - n * kt;
+                wl[k * S + n] = w[(long)(nl0 + n) * w_sn + k0 + k];
+            }
+        } else {
+            for (int e = tid; e < 16 * NT * kt; e += 256) {
+                const int k = e / (16 * NT), n = e - k * 16 * NT;
+                wl[k * S + n] = w[(long)(nl0 + n) * w_sn + (long)(k0 + k) * w_sk];
+            }
         }
-        if (act_in) {
+        __syncthreads();
+        if (!live) continue;
+        for (int c = k0 / 16; c < (k0 + kt) / 16; ++c) {
+            if (c + 1 < nchunk) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s) xn[s] = *reinterpret_cast<const floatx4*>(xb + (size_t)(16 * (c + 1) + 4 * q + s) * P);
+            }
+            if (act_in) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xv[s][t] = gelu_f(xv[s][t]);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xv[s][t] = gelu_f(xv[s][t]);
+            }
+            const float* wrow = wl + (16 * c - k0 + 4 * q) * S + m;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = wrow[s * S + 16 * nt];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s][t], bf[nt], acc[nt][t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xv[s] = xn[s];
         }
-        const float* wrow = wl + (16 * c + 4 * q) * S + m;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float bf[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = wrow[s * S + 16 * nt];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s][t], bf[nt], acc[nt][t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) xv[s] = xn[s];
+    }
+    if (!live) {
+        if (stat_part) __syncthreads(), __syncthreads();     // the statistics epilogue's two barriers (host: P % 256 == 0 there, so never taken)
+        return;
     }
 
     // epilogue: lane owns channel n0 + 16nt + m, pixels p0 + 16i + 4q + t
@@ -410,7 +421,7 @@ template <int NT>
 int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, const float* addend,
                 float* y, int B, int K, int N, int P, int act_in, hipStream_t st, int G, long w_sg, const float* bscale,
                 float* stat_part) {
-    const size_t lds = (size_t)K * lds_stride(NT) * sizeof(float);
+    const size_t lds = (size_t)(K < KT_MAX ? K : KT_MAX) * lds_stride(NT) * sizeof(float);
     KMU_MAX_LDS((pw_gemm_kernel<NT>), lds);
     hipLaunchKernelGGL((pw_gemm_kernel<NT>), dim3(B * ((P + 255) / 256), N / (16 * NT)), dim3(256), lds, st, x, w, w_sn, w_sk, bias,
                        mul_pre, addend, y, K, N, P, act_in, G, w_sg, bscale, stat_part);
@@ -425,7 +436,6 @@ int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk,
                 what, K, N);
     KMU_REQUIRE(G >= 1 && N % (16 * G) == 0, "%s: %d output channels do not split into %d groups of whole 16-channel tiles", what, N, G);
     KMU_REQUIRE(P > 0 && P % 64 == 0, "%s: H*W = %d must be a positive multiple of 64", what, P);
-    KMU_REQUIRE(K <= 256, "%s: %d contraction channels exceed the LDS weight tile (256)", what, K);
     // With few pixel blocks (the 32x32 level: B*P/256 = 32) a 4-tile-wide workgroup leaves most of the 256 CUs idle and walks all K
     // channels on its own: 27.6 us for 256 -> 64 at [8, ., 32, 32] (0.38 TB/s).  Narrower channel tiles there give grid.y more
     // workgroups; x is re-read from L2 once per channel tile, which at these sizes (<= 8 MB) is cheaper than an idle device.

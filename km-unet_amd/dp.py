@@ -141,7 +141,14 @@ class DataParallel:
         self.bucket.store(grads)
 
     def all_reduce_grads(self):
+        """Average the flat gradient bucket over the ranks: ONE collective.  On RCCL the 1 / world factor rides in the reduction
+        itself (ncclAvg) -- no separate division launch between the two captured graphs; gloo (CPU tests) has no averaging
+        reduction, so it sums and divides."""
         if not self.collective:
             return
-        dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
-        self.bucket.flat.div_(self.world)
+        if dist.get_backend(self.pg) == "nccl":
+            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.AVG, group=self.pg)
+        else:
+            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.world > 1:
+                self.bucket.flat.div_(self.world)

@@ -677,14 +677,19 @@ class DeformSampleFn(torch.autograd.Function):
 
 
 def deform_conv2d(x, offset, weight, bias=None):
-    """Deformable 3x3 conv = sampling kernel (columns) + a [Cout, Cin*9] GEMM (rocBLAS through torch.matmul; its two
-    backward GEMMs replace 4.7 M float atomics of the fused kernel's weight gradient)."""
+    """Deformable 3x3 conv = sampling kernel (columns) + a [Cout, Cin*9] contraction on the pointwise-conv kernels (its two backward
+    contractions replace 4.7 M float atomics of the fused kernel's weight gradient)."""
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     if tuple(weight.shape[1:]) != (Cin, 3, 3) or tuple(offset.shape) != (B, 18, H, W):
         raise RuntimeError("DeformConv2d: only 3x3/stride1/pad1/one offset group is built (weight %s, offset %s)"
                            % (tuple(weight.shape), tuple(offset.shape)))
-    y = torch.matmul(weight.reshape(Cout, Cin * 9), DeformSampleFn.apply(x, offset))
+    cols = DeformSampleFn.apply(x, offset)
+    if pwconv_supported(Cin * 9, Cout, H * W):
+        # the [Cout, Cin*9] x [Cin*9, HW] product is a 1x1 convolution over the sampled columns: the pointwise-conv kernels (forward,
+        # input gradient, weight + bias gradient), contraction tiled over 256 channels at a time -- no rocBLAS call on the model's path
+        return pwconv(cols.view(B, Cin * 9, H, W), weight.reshape(Cout, Cin * 9), bias)
+    y = torch.matmul(weight.reshape(Cout, Cin * 9), cols)      # shapes outside the kernels' tiling (tests: 8 channels, 7 x 9 pixels)
     if bias is not None:
         y = y + bias.view(1, -1, 1)
     return y.view(B, Cout, H, W)
@@ -1571,7 +1576,7 @@ def qkv_gate(qkv):
 
 # ------------------------------------------------------------------------------------------ pointwise conv
 def pwconv_supported(ci, co, hw):
-    return ci % 16 == 0 and co % 16 == 0 and 0 < ci <= 256 and 0 < co <= 256 and hw % 64 == 0
+    return ci % 16 == 0 and co % 16 == 0 and 0 < ci <= 1024 and 0 < co <= 1024 and hw % 64 == 0
 
 
 class PwConvFn(torch.autograd.Function):

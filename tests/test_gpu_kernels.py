@@ -490,6 +490,8 @@ def test_qkv_gate_vs_torch_cpu():
     (3, 32, 32, 16, 8, True, False),      # 'channel' projection; P = 128 leaves waves idle in the 256-pixel block
     (2, 48, 16, 8, 8, True, True),        # 3-tile contraction, 1-tile output
     (8, 16, 64, 128, 128, True, False),   # bench shape: every wave walks several chunks in bwd_weight
+    (2, 576, 64, 16, 16, True, False),    # DAGEM's deformable-conv contraction over Cin * 9 sampled columns: 3 weight tiles of <= 256 channels
+    (1, 320, 32, 8, 8, False, True),      # two weight tiles (256 + 64), GELU on load
 ])
 def test_pwconv_vs_torch_cpu(B, Ci, Co, H, W, bias, gelu):
     """Pointwise conv kernels (csrc/pwconv.hip) against torch's fp64 CPU conv2d (+ exact GELU)."""

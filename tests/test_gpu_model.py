@@ -69,7 +69,7 @@ def test_whole_model_golden(name, variant, nc, train):
     got = {"<input>": x.grad.cpu()}
     got.update({k: v.cpu() for k, v in grads.items()})
     ok, rep = ties.explain_by_masks(o64, g["x"].double(), lambda out: torch.nn.functional.mse_loss(out, tgt), got, masks,
-                                    tie_rel=2e-4, tol=2e-3)
+                                    tie_rel=5e-5, tol=2e-3)
     print("  [%s] tie analysis: %s" % (name, ties.describe_masks(rep)))
     assert ok, ties.describe_masks(rep)
 
