@@ -232,7 +232,7 @@ def test_bench_rccl_single_rank():
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[:3000] + "\n...\n" + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["collective"].startswith("nccl all-reduce of")
+    assert line["n_gpus"] == 1 and line["collective"].startswith("nccl all-reduce (average) of") and "1 rank(s)" in line["collective"]
     assert line["launch_mode"] == "hipGraph replay" and 0.0 < line["loss"] <= 1.5 * line["loss_first"] + 1e-3
 
 
