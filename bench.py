@@ -128,6 +128,12 @@ def _kernel_model(name, shape):
     if name.startswith("dagem_edges"):
         B, C, H, W = shape
         return "hbm", 0.0, t * B * C * H * W * (5 if name.endswith("fwd") else 6)
+    if name.startswith("bn_blend_bwd_partials"):
+        B, C, HW = shape
+        return "hbm", 0.0, t * B * C * HW * 3
+    if name.startswith("dwconv3x3_bn_bwd"):
+        B, C, H, W = shape
+        return "hbm", 24.0 * B * C * H * W, t * B * C * H * W * 3
     if name.startswith("dwconv3x3"):
         B, C, H, W = shape[:4] if len(shape) >= 4 else (shape[0], shape[1], 1, 1)
         return "hbm", 18.0 * B * C * H * W, t * B * C * H * W * 2

@@ -592,6 +592,22 @@ int kmu_ffn_fused_bwd(const float* g, const float* x, const float* z2, const flo
                       float* d_alpha, float* slab_w1, float* slab_w2, void* ws, size_t ws_bytes, int B, int C, int P, int stage,
                       kmu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * EfficientViMBlock's dwconv stage backward with the BatchNorm folded into the stencil (round 3): x + a (BN(dwconv3x3(x)) - x),
+ * efficient_vim_init.py:85,93 with ConvLayer2D = conv + BatchNorm2d, vim_utils_init.py:62-89.
+ *   kmu_bn_blend_bwd_partials   the reduction half of kmu_bn_blend_bwd: part [C][S][3], S = kmu_bn_blend_splits
+ *   kmu_dwconv3x3_bn_bwd_data   dx = dwconv^T(dt) + (1 - a) g with dt (BatchNorm's input gradient) formed on the fly from (g, t) and the
+ *                               folded partials; also d_gamma, d_beta, d_alpha and the per-channel constants cst [C][4]
+ *   kmu_dwconv3x3_bn_bwd_weight d weight partials [kmu_dwconv3x3_partials][C][9] from (x, g, t, cst): dt is never materialised
+ * ------------------------------------------------------------------------------------ */
+int kmu_bn_blend_bwd_partials(const float* gout, const float* t, const float* x, const float* gamma, const float* beta, const float* alpha,
+                              const float* stats, int relu, float* part, int B, int C, int HW, kmu_stream_t stream);
+int kmu_dwconv3x3_bn_bwd_data(const float* g, const float* t, const float* weight, const float* gamma, const float* alpha, const float* stats,
+                              const float* part, int S, int training, float* dx, float* d_gamma, float* d_beta, float* d_alpha, float* cst,
+                              int B, int C, int H, int W, kmu_stream_t stream);
+int kmu_dwconv3x3_bn_bwd_weight(const float* x, const float* g, const float* t, const float* cst, float* d_weight_partial, int B, int C,
+                                int H, int W, kmu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,9 @@ SIGNATURES = {
     "kmu_ffn_fused_bwd_ws_bytes": (_Z, [_I] * 3),
     "kmu_ffn_fused_fwd": (_I, [_P] * 7 + [_c.c_float] * 2 + [_P] * 6 + [_c.c_float] * 2 + [_P, _I] + [_P] * 6 + [_Z] + [_I] * 4 + [_P]),
     "kmu_ffn_fused_bwd": (_I, [_P] * 12 + [_I] + [_P] * 9 + [_Z] + [_I] * 4 + [_P]),
+    "kmu_bn_blend_bwd_partials": (_I, [_P] * 7 + [_I, _P] + [_I] * 3 + [_P]),
+    "kmu_dwconv3x3_bn_bwd_data": (_I, [_P] * 7 + [_I, _I] + [_P] * 5 + [_I] * 4 + [_P]),
+    "kmu_dwconv3x3_bn_bwd_weight": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),
 }
 

@@ -329,3 +329,18 @@ extern "C" int kmu_bn_blend_bwd(const float* gout, const float* t, const float* 
                        training, dt, dx, d_gamma, d_beta, d_alpha, B, C, HW, sp.chunk);
     return kmu::launch_status("bn_blend_bwd apply");
 }
+
+// The reduction half of kmu_bn_blend_bwd alone: partials [C][S][3] (S = kmu_bn_blend_splits) of (sum dz, sum dz that, sum g (f - x)).
+// For callers that fold the apply half into their own kernel (kmu_dwconv3x3_bn_bwd_data).
+extern "C" int kmu_bn_blend_bwd_partials(const float* gout, const float* t, const float* x, const float* gamma, const float* beta,
+                                         const float* alpha, const float* stats, int relu, float* part, int B, int C, int HW,
+                                         kmu_stream_t stream) {
+    KMU_REQUIRE(gout && t && part, "bn_blend_bwd_partials: null pointer");
+    KMU_REQUIRE(!gamma || (beta && stats), "bn_blend_bwd_partials: BatchNorm needs beta, stats");
+    KMU_REQUIRE(!alpha || x, "bn_blend_bwd_partials: a blend needs x");
+    KMU_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0, "bn_blend_bwd_partials: bad dims");
+    const Split sp = split_for(B, HW);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, sp.S), dim3(256), 0, (hipStream_t)stream, gout, t, x, gamma, beta, alpha, stats, relu,
+                       part, B, C, HW, sp.chunk);
+    return kmu::launch_status("bn_blend_bwd_partials");
+}

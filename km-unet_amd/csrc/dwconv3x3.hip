@@ -212,6 +212,126 @@ __global__ __launch_bounds__(256) void dwconv3x3_scaled_finish_kernel(const floa
     }
 }
 
+
+// ---- EfficientViMBlock's dwconv stage backward, BatchNorm folded in (efficient_vim_init.py:85,93: x + a (BN(dwconv(x)) - x)) -----------
+// g = d loss / d out.  With t = dwconv(x) saved and (sum dz, sum dz that, sum g (BN(t) - x)) per channel left as partials by
+// bn_bwd_reduce_kernel (csrc/bn_blend.hip), the gradient of t is an affine function of (g, t) per channel,
+//        dt = k (a g - m0 - that m1) = A g + B t + D,        that = (t - mean) rstd,  k = gamma rstd,
+// so the separate BatchNorm-backward apply pass (read g, t; write dt, dxb) disappears: the transposed stencil evaluates dt at its 18
+// taps on the fly (0 outside the image) and adds the blend partner's gradient (1 - a) g at the centre:
+//        dx = dwconv^T(dt) + (1 - a) g.
+// Every workgroup folds the <= 32 partial triples of all C channels itself (fixed order, double, as bn_bwd_apply_kernel does);
+// workgroup 0 writes d_gamma / d_beta / d_alpha and the constants table cst [C][4] = {A, B, D, 1 - a} that the weight-gradient
+// kernel (off the activation-gradient chain) reads to form the same dt.
+__global__ __launch_bounds__(256) void dwconv3x3_bn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ t,
+                                                               const float* __restrict__ w, const float* __restrict__ gamma,
+                                                               const float* __restrict__ alpha, const float* __restrict__ stats,
+                                                               const float* __restrict__ part, int S, int training, double N,
+                                                               float* __restrict__ dx, float* __restrict__ d_gamma,
+                                                               float* __restrict__ d_beta, float* __restrict__ d_alpha,
+                                                               float* __restrict__ cst_out, int C, int H, int W, size_t total) {
+    extern __shared__ __attribute__((aligned(16))) float cst[];      // [C][4]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+        for (int i = 0; i < S; ++i) {
+            const float* p = part + ((size_t)c * S + i) * 3;
+            q0 += p[0], q1 += p[1], q2 += p[2];
+        }
+        const float mean = stats[2 * c], rstd = stats[2 * c + 1], a = 1.f / (1.f + __expf(-alpha[c]));
+        const float k = gamma[c] * rstd;
+        const float m0 = training ? (float)(q0 / N) : 0.f, m1 = training ? (float)(q1 / N) : 0.f;
+        const floatx4 v = {k * a, -k * m1 * rstd, k * (m1 * rstd * mean - m0), 1.f - a};
+        reinterpret_cast<floatx4*>(cst)[c] = v;
+        if (blockIdx.x == 0) {
+            reinterpret_cast<floatx4*>(cst_out)[c] = v;
+            d_gamma[c] = (float)q1;
+            d_beta[c] = (float)q0;
+            d_alpha[c] = (float)q2 * a * (1.f - a);
+        }
+    }
+    __syncthreads();
+    const int W4 = W >> 2;          // host: W % 4 == 0
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x0 = (int)(e % W4) * 4;
+        size_t r = e / W4;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C);
+        const floatx4 k = reinterpret_cast<const floatx4*>(cst)[c];
+        const size_t plane = r * (size_t)H * W;
+        float wv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wv[i] = w[c * 9 + 8 - i];       // transposed stencil: flipped taps
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        floatx4 gc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const size_t o = plane + (size_t)yy * W + x0;
+            const floatx4 gm = *reinterpret_cast<const floatx4*>(g + o), tm = *reinterpret_cast<const floatx4*>(t + o);
+            if (dy == 1) gc = gm;
+            float v[6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[1 + i] = fmaf(k[0], gm[i], fmaf(k[1], tm[i], k[2]));
+            v[0] = x0 > 0 ? fmaf(k[0], g[o - 1], fmaf(k[1], t[o - 1], k[2])) : 0.f;
+            v[5] = x0 + 4 < W ? fmaf(k[0], g[o + 4], fmaf(k[1], t[o + 4], k[2])) : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int dxx = 0; dxx < 3; ++dxx) acc[q] += wv[dy * 3 + dxx] * v[q + dxx];
+        }
+        floatx4 o4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o4[q] = fmaf(k[3], gc[q], acc[q]);
+        *reinterpret_cast<floatx4*>(dx + plane + (size_t)y * W + x0) = o4;
+    }
+}
+
+// the weight gradient of the same stage: dw[c][tap] partial = sum dt[p] x[p + tap - centre] with dt = A g + B t + D formed on the fly
+__global__ __launch_bounds__(256) void dwconv3x3_bn_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                      const float* __restrict__ t, const float* __restrict__ cst,
+                                                                      float* __restrict__ dw_part, int C, int H, int W) {
+    __shared__ float red[4][9];
+    const int c = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int rows = (H + WSPLIT - 1) / WSPLIT, y0 = sp * rows, y1 = min(H, y0 + rows);
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* xp = x + plane;
+    const floatx4 k = reinterpret_cast<const floatx4*>(cst)[c];
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    const int W4 = W >> 2, nstrip = max(0, y1 - y0) * W4;
+    for (int sidx = threadIdx.x; sidx < nstrip; sidx += 256) {
+        const int y = y0 + sidx / W4, x0 = (sidx % W4) * 4;
+        const floatx4 gv = *reinterpret_cast<const floatx4*>(g + plane + (size_t)y * W + x0), tv = *reinterpret_cast<const floatx4*>(t + plane + (size_t)y * W + x0);
+        float g4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g4[q] = fmaf(k[0], gv[q], fmaf(k[1], tv[q], k[2]));
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+            const int yy = y + dyy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float* row = xp + (size_t)yy * W;
+            const floatx4 m = *reinterpret_cast<const floatx4*>(row + x0);
+            const float v[6] = {x0 > 0 ? row[x0 - 1] : 0.f, m[0], m[1], m[2], m[3], x0 + 4 < W ? row[x0 + 4] : 0.f};
+#pragma unroll
+            for (int dxx = 0; dxx < 3; ++dxx)
+                acc[dyy * 3 + dxx] += (g4[0] * v[dxx] + g4[1] * v[dxx + 1]) + (g4[2] * v[dxx + 2] + g4[3] * v[dxx + 3]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float s = kmu::wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        dw_part[(((size_t)b * WSPLIT + sp) * C + c) * 9 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 int launch_stencil(const float* in, const float* w, const float* bias, const float* scale, float* out, int B, int C, int H, int W,
                    int flip, hipStream_t st, const char* what, const float* addend = nullptr) {
     const size_t total = (size_t)B * C * H * ((W + 3) / 4);
@@ -297,4 +417,29 @@ extern "C" int kmu_dwconv3x3_bwd_data_add(const float* dy, const float* weight, 
     KMU_REQUIRE(dy && weight && addend && dx, "dwconv3x3_bwd_data_add: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_bwd_data_add: bad dims");
     return launch_stencil(dy, weight, nullptr, nullptr, dx, B, C, H, W, 1, (hipStream_t)stream, "dwconv3x3_bwd_data_add", addend);
+}
+
+// EfficientViMBlock's dwconv stage backward behind kmu_bn_blend_bwd_partials (csrc/bn_blend.hip): dx = dwconv^T(dt) + (1 - a) g with
+// dt = BatchNorm2d's input gradient formed on the fly from (g, t) and the folded partials (efficient_vim_init.py:85,93;
+// vim_utils_init.py:62-89).  part [C][S][3] and S as kmu_bn_blend_bwd_partials left them; stats [C][2] = (mean, rstd) of the forward;
+// cst [C][4]: written here, read by kmu_dwconv3x3_bn_bwd_weight (d weight partials [B * 4][C][9], kmu_dwconv3x3_partials rows).
+extern "C" int kmu_dwconv3x3_bn_bwd_data(const float* g, const float* t, const float* weight, const float* gamma, const float* alpha,
+                                         const float* stats, const float* part, int S, int training, float* dx, float* d_gamma,
+                                         float* d_beta, float* d_alpha, float* cst, int B, int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(g && t && weight && gamma && alpha && stats && part && dx && d_gamma && d_beta && d_alpha && cst, "dwconv3x3_bn_bwd_data: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && C <= 4096 && H > 0 && W > 0 && W % 4 == 0 && S > 0, "dwconv3x3_bn_bwd_data: bad dims (W %% 4 == 0 required)");
+    const size_t total = (size_t)B * C * H * (W / 4);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dwconv3x3_bn_bwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * 16, (hipStream_t)stream, g, t, weight, gamma, alpha,
+                       stats, part, S, training, (double)B * H * W, dx, d_gamma, d_beta, d_alpha, cst, C, H, W, total);
+    return kmu::launch_status("dwconv3x3_bn_bwd_data");
+}
+
+extern "C" int kmu_dwconv3x3_bn_bwd_weight(const float* x, const float* g, const float* t, const float* cst, float* d_weight_partial, int B,
+                                           int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && g && t && cst && d_weight_partial, "dwconv3x3_bn_bwd_weight: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && W % 4 == 0, "dwconv3x3_bn_bwd_weight: bad dims (W %% 4 == 0 required)");
+    hipLaunchKernelGGL(dwconv3x3_bn_bwd_weight_kernel, dim3(C, B, WSPLIT), dim3(256), 0, (hipStream_t)stream, x, g, t, cst, d_weight_partial, C, H, W);
+    return kmu::launch_status("dwconv3x3_bn_bwd_weight");
 }

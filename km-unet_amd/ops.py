@@ -1395,6 +1395,31 @@ class DwBnBlendFn(torch.autograd.Function):
         training, wshape = ctx.cfg
         B, C, H, W = x.shape
         st = _stream()
+        if W % 4 == 0 and C <= 4096:
+            # BatchNorm's backward folded into the transposed stencil: reduce (partials), then dx = dwconv^T(dt) + (1 - a) g with dt
+            # formed on the fly from (g, t) -- no dt / dxb tensors, one launch less on the activation-gradient chain
+            g = _f32c(g, "grad")
+            dev = x.device
+            S = lib.kmu_bn_blend_splits(B, H * W)
+            part = torch.empty(C * S * 3, device=dev, dtype=torch.float32)
+            _lib.check(_call(("bn_blend_bwd_partials", (B, C, H * W)), lib.kmu_bn_blend_bwd_partials, _ptr(g), _ptr(t), _ptr(x), _ptr(gamma),
+                             _ptr(beta), _ptr(a_row), _ptr(stats), 0, _ptr(part), B, C, H * W, st), "kmu_bn_blend_bwd_partials")
+            dx = torch.empty_like(x)
+            dg, db, da = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(3))
+            cst = torch.empty(C, 4, device=dev, dtype=torch.float32)
+            _lib.check(_call(("dwconv3x3_bn_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_bn_bwd_data, _ptr(g), _ptr(t), _ptr(w), _ptr(gamma),
+                             _ptr(a_row), _ptr(stats), _ptr(part), S, training, _ptr(dx), _ptr(dg), _ptr(db), _ptr(da), _ptr(cst), B, C, H, W,
+                             st), "kmu_dwconv3x3_bn_bwd_data")
+            dw = torch.empty(C, 9, device=dev, dtype=torch.float32)
+
+            def job():
+                P = lib.kmu_dwconv3x3_partials(B)
+                dwp = torch.empty(P, C, 9, device=dev, dtype=torch.float32)
+                _lib.check(_call(("dwconv3x3_bn_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bn_bwd_weight, _ptr(x), _ptr(g), _ptr(t), _ptr(cst),
+                                 _ptr(dwp), B, C, H, W, _stream()), "kmu_dwconv3x3_bn_bwd_weight")
+                colsum(dwp, outs=[dw])
+            _wgrad(job, ctx.defer_wgrad)
+            return dx, dw.view(wshape), dg, db, da, None, None, None, None, None, None
         dt, dxb, dg, db, da = _k_bn_bwd(lib, _f32c(g, "grad"), t, x, gamma, beta, a_row, stats, 0, training)
         dx = torch.empty_like(x)
         _lib.check(_call(("dwconv3x3_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_data_add, _ptr(dt), _ptr(w), _ptr(dxb), _ptr(dx), B, C, H, W,

@@ -883,6 +883,37 @@ def test_ffn_fused_matches_unfused_kernels(monkeypatch):
         res.append((y, xd.grad, ad.grad, f.fc1.conv.weight.grad, f.fc2.conv.weight.grad, f.fc1.norm.weight.grad, f.fc2.norm.bias.grad))
     _report("ffn fused vs unfused", **{n: rel_err(a, b) for n, a, b in zip(("y", "dx", "da", "dw1", "dw2", "dg1", "db2"), res[0], res[1])})
 
+
+@pytest.mark.parametrize("B,C,H,W,train", [(8, 16, 128, 128, True), (2, 32, 16, 16, True), (3, 64, 8, 12, True), (2, 16, 32, 32, False),
+                                           (2, 16, 6, 10, True)])
+def test_dw_bn_blend_vs_torch_cpu(B, C, H, W, train):
+    """EfficientViMBlock's dwconv stage (efficient_vim_init.py:85,93), x + sigmoid(a) (BN(dwconv3x3(x)) - x), as one autograd node
+    against torch fp64 on the CPU; the backward folds BatchNorm's input gradient into the transposed stencil (W % 4 == 0) -- the last
+    shape takes the unfused kernels."""
+    import copy
+    import torch.nn as nn
+    ops = _ops()
+    gen = torch.Generator().manual_seed(11 * C + H)
+    conv = nn.Conv2d(C, C, 3, padding=1, groups=C, bias=False)
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(C, generator=gen)); bn.bias.copy_(0.2 * torch.randn(C, generator=gen))
+        bn.running_mean.copy_(0.1 * torch.randn(C, generator=gen)); bn.running_var.copy_(0.5 + torch.rand(C, generator=gen))
+    alpha = torch.randn(C, generator=gen)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.5 + 0.3
+    gy = torch.randn(B, C, H, W, generator=gen)
+    cr, br = copy.deepcopy(conv).double(), copy.deepcopy(bn).double().train(train)
+    xo, ao = x.double().requires_grad_(True), alpha.double().requires_grad_(True)
+    yo = torch.lerp(xo, br(cr(xo)), torch.sigmoid(ao).view(1, C, 1, 1))
+    yo.backward(gy.double())
+    cd, bd = copy.deepcopy(conv).to(DEV), copy.deepcopy(bn).to(DEV).train(train)
+    xd, ad = x.to(DEV).requires_grad_(True), alpha.to(DEV).requires_grad_(True)
+    y = ops.dw_bn_blend(xd, cd, bd, ad)
+    y.backward(gy.to(DEV))
+    _report("dw_bn_blend %s" % ((B, C, H, W, train),), y=rel_err(y, yo), dx=rel_err(xd.grad, xo.grad), dalpha=rel_err(ad.grad, ao.grad),
+            dw=rel_err(cd.weight.grad, cr.weight.grad), dgamma=rel_err(bd.weight.grad, br.weight.grad), dbeta=rel_err(bd.bias.grad, br.bias.grad),
+            rmean=rel_err(bd.running_mean, br.running_mean), rvar=rel_err(bd.running_var, br.running_var))
+
 # ------------------------------------------------------------------------------------------ blocks
 @pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
 def test_evim_block_golden(name, train):
