@@ -104,6 +104,10 @@ def _kernel_model(name, shape):
         flops = 2.0 * B * P * Ci * Co
         extra = B * P * Ci if name.endswith("bwd_input") else 0     # GELU'(x_pre) operand (upper bound: only with gelu_in)
         return "hbm", flops, t * (B * P * (Ci + Co) + Ci * Co) + 0 * extra
+    if name.startswith("tail_ffn"):   # csrc/ffn_fused.hip: fwd reads nrm, x and writes out; bwd reads nrm, g and writes dn
+        B, C, P = shape
+        prod = 2.0 * B * P * C * 4 * C
+        return "hbm", (2 if name.endswith("fwd") else 5) * prod, t * B * C * P * 3
     if name.startswith("ffn_"):       # csrc/ffn_fused.hip: [B,C,P] tensors read / written once per pass, 4C hidden channels recomputed
         B, C, P = shape
         prod = 2.0 * B * P * C * 4 * C                               # one C x 4C product over all pixels

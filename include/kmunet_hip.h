@@ -608,6 +608,18 @@ int kmu_dwconv3x3_bn_bwd_data(const float* g, const float* t, const float* weigh
 int kmu_dwconv3x3_bn_bwd_weight(const float* x, const float* g, const float* t, const float* cst, float* d_weight_partial, int B, int C,
                                 int H, int W, kmu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * EnhancedViMBlock's FFN tail as recompute kernels (round 3): out = x + s[b] (W2 gelu(W0 nrm + b0) + b2) with nrm = TripleNorm(x)
+ * made by kmu_triple_norm_fwd (KM_UNetV3_SH.py:120-124 ffn, :147-150; s = DropPath's per-sample factor or NULL).  One launch each
+ * way, the 4C-wide hidden tensor is never stored: bwd re-derives W0 nrm, returns dn = d loss / d nrm and per-workgroup partials
+ * slab_w0 [rows][4C][C], slab_w2 [rows][C][4C], rows_b [rows][4C + C] (d b0 | d b2), rows = kmu_ffn_fused_rows(B, C, P, 1).
+ * Shapes: kmu_ffn_fused_supported.
+ * ------------------------------------------------------------------------------------ */
+int kmu_tail_ffn_fwd(const float* nrm, const float* x, const float* w0, const float* b0, const float* w2, const float* b2,
+                     const float* sdp, float* out, int B, int C, int P, kmu_stream_t stream);
+int kmu_tail_ffn_bwd(const float* nrm, const float* g, const float* w0, const float* b0, const float* w2, const float* sdp, float* dn,
+                     float* slab_w0, float* slab_w2, float* rows_b, int B, int C, int P, kmu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

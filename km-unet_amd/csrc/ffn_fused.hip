@@ -981,6 +981,376 @@ __global__ __launch_bounds__(Cfg<C>::NTHR) void ffn_bwd_kernel(BArgs a) {
     }
 }
 
+// ============================================================================================================ EnhancedViMBlock tail
+// out = x + s[b] * ( W2 gelu(W0 n + b0) + b2 ),  n = TripleNorm(x)  (KM_UNetV3_SH.py:120-124 ffn, :147-150; s = DropPath's per-sample
+// factor or NULL).  The same recompute scheme without the BatchNorms: the 4C-wide hidden tensor is never stored -- ONE launch forward
+// (orientation N: W0 n -> GELU on the registers -> W2, bias / DropPath factor / residual in the epilogue) and ONE backward (D'):
+//   pre = W0 n + b0,  df = s g,  dh = (W2^T df) gelu'(pre),  dn = W0^T dh,  dW2 = sum df gelu(pre)^T,  dW0 = sum dh n^T,  db0 = sum dh,
+//   db2 = sum df  -- no statistics stand between the products, so nothing needs a second pass.  TripleNorm keeps its own kernels
+//   (csrc/triple_norm.hip) in front of / behind these.
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+    return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+}
+
+template <int C>
+struct TailFwdLds {
+    using K = Cfg<C>;
+    static constexpr size_t BYTES = K::JS == 1 ? 16 : (size_t)K::NW * C * K::TS * 4;
+};
+
+template <int C>
+__global__ __launch_bounds__(Cfg<C>::NTHR) void tail_ffn_fwd_kernel(const float* __restrict__ nrm, const float* __restrict__ x,
+                                                                    const float* __restrict__ w0, const float* __restrict__ b0,
+                                                                    const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                    const float* __restrict__ sdp, float* __restrict__ out, int P,
+                                                                    int ntiles) {
+    using K = Cfg<C>;
+    typedef typename K::VT VT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* redz = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int grp = wave / K::JS, slice = wave % K::JS, j0 = slice * K::SW;
+    float w1r[K::NTW][4 * K::CC];
+    load_w1r<C>(w0, j0, m, q, w1r);
+    floatx4 w2r[K::CC][K::NTW], b0v[K::NTW];
+#pragma unroll
+    for (int nt = 0; nt < K::NTW; ++nt) {
+        b0v[nt] = *reinterpret_cast<const floatx4*>(b0 + j0 + 16 * nt + 4 * q);
+#pragma unroll
+        for (int ct = 0; ct < K::CC; ++ct)
+            w2r[ct][nt] = *reinterpret_cast<const floatx4*>(w2 + (size_t)(16 * ct + m) * K::HID + j0 + 16 * nt + 4 * q);
+    }
+    const int gtid = tid - grp * K::JS * 64;
+    const int per_it = gridDim.x * K::TG, unit0 = blockIdx.x * K::TG + grp;
+    const int iters = (ntiles + per_it - 1) / per_it;
+    for (int it = 0; it < iters; ++it) {
+        const int tile = unit0 + it * per_it;
+        const bool valid = tile < ntiles;
+        int b = 0, p0 = 0;
+        if (valid) tile_of<C>(tile, P, b, p0);
+        const float sb = (valid && sdp) ? sdp[b] : 1.f;
+        floatx4 d2[K::CC][K::TT];
+        if (valid) {
+            const float* nt_ = nrm + (size_t)b * C * P + p0;
+            floatx4 d1[K::NTW][K::TT];
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt) zero(d1[nt]);
+#pragma unroll
+            for (int cc = 0; cc < K::CC; ++cc) {
+                VT xa[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const VT*>(nt_ + (size_t)(16 * cc + 4 * q + s) * P + K::TT * m);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) mfma(d1[nt][t], w1r[nt][4 * cc + s], xa[s][t]);
+            }
+            drain(d1);
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                for (int t = 0; t < K::TT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d1[nt][t][i] = gelu_f(d1[nt][t][i] + b0v[nt][i]);
+#pragma unroll
+            for (int ct = 0; ct < K::CC; ++ct) zero(d2[ct]);
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) mfma(d2[ct][t], w2r[ct][nt][i], d1[nt][t][i]);
+            drain(d2);
+        }
+        if constexpr (K::JS == 1) {
+            if (valid) {
+#pragma unroll
+                for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 16 * ct + 4 * q + i;
+                        const size_t o = ((size_t)b * C + c) * P + p0 + K::TT * m;
+                        const VT xv = *reinterpret_cast<const VT*>(x + o);
+                        const float bb = b2[c];
+                        VT v;
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) v[t] = fmaf(sb, d2[ct][t][i] + bb, xv[t]);
+                        *reinterpret_cast<VT*>(out + o) = v;
+                    }
+            }
+        } else {
+            if (valid) {
+#pragma unroll
+                for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        VT v;
+#pragma unroll
+                        for (int t = 0; t < K::TT; ++t) v[t] = d2[ct][t][i];
+                        *reinterpret_cast<VT*>(redz + (size_t)(wave * C + 16 * ct + 4 * q + i) * K::TS + K::TT * m) = v;
+                    }
+            }
+            __syncthreads();
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = gtid + k * K::JS * 64, c = e >> 4, pg = e & 15;
+                    const float* src = redz + (size_t)(grp * K::JS * C + c) * K::TS + K::TT * pg;
+                    VT v = *reinterpret_cast<const VT*>(src);
+#pragma unroll
+                    for (int w = 1; w < K::JS; ++w) v += *reinterpret_cast<const VT*>(src + (size_t)w * C * K::TS);
+                    const size_t o = ((size_t)b * C + c) * P + p0 + K::TT * pg;
+                    const VT xv = *reinterpret_cast<const VT*>(x + o);
+                    const float bb = b2[c];
+#pragma unroll
+                    for (int t = 0; t < K::TT; ++t) v[t] = fmaf(sb, v[t] + bb, xv[t]);
+                    *reinterpret_cast<VT*>(out + o) = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int C>
+struct TailBwdLds {
+    using K = Cfg<C>;
+    static constexpr int T_F = K::NW * 16 * K::TS;
+    static constexpr int COMB_F = K::TG > 1 ? K::TG * (C * K::HID + K::HID + C) : 4;
+    static constexpr int MAIN_F = T_F > COMB_F ? T_F : COMB_F;
+    static constexpr int WL_F = K::HID * (C + 4);
+    static constexpr size_t BYTES = (size_t)(WL_F + MAIN_F) * 4;
+};
+
+struct TailBArgs {
+    const float *nrm, *g, *w0, *b0, *w2, *sdp;
+    float *dn, *slab_w0, *slab_w2, *rows_b;     // rows_b [G][HID + C]: db0 | db2 partial sums
+    int P, ntiles;
+};
+
+template <int C>
+__global__ __launch_bounds__(Cfg<C>::NTHR) void tail_ffn_bwd_kernel(TailBArgs a) {
+    using K = Cfg<C>;
+    typedef typename K::VT VT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                       // W0 [HID][C + 4]
+    float* T = wl + TailBwdLds<C>::WL_F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int slice = wave % K::JS, grp = wave / K::JS, j0 = slice * K::SW;
+    const int P = a.P;
+    float w1r[K::NTW][4 * K::CC], w2r[K::NTW][4 * K::CC], b0v[K::NTW];
+    load_w1r<C>(a.w0, j0, n, q, w1r);
+    load_w2r<C>(a.w2, j0, n, q, w2r);
+#pragma unroll
+    for (int nt = 0; nt < K::NTW; ++nt) b0v[nt] = a.b0[j0 + 16 * nt + n];
+    for (int e = tid; e < K::HID * C; e += K::NTHR) {
+        const int j = e / C, c = e - j * C;
+        wl[j * (C + 4) + c] = a.w0[e];
+    }
+    __syncthreads();
+    floatx4 acc0[K::CC][K::NTW], acc2[K::CC][K::NTW];     // dW0 tile (rows j, column c = 16ct + n); dW2 tile (rows c = 16ct + 4q + i, column j)
+#pragma unroll
+    for (int ct = 0; ct < K::CC; ++ct) zero(acc0[ct]), zero(acc2[ct]);
+    float sb0[K::NTW], sb2[K::CC];
+#pragma unroll
+    for (int nt = 0; nt < K::NTW; ++nt) sb0[nt] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < K::CC; ++ct) sb2[ct] = 0.f;
+    const int poff = K::TT * fperm(n);
+    constexpr int DN = K::JS == 1 ? K::TT : 2;
+    typedef typename Vec<DN>::type DV;
+    const int own_ct = K::JS == 1 ? 0 : slice % K::CC;
+    const int own_t0 = (K::JS == 1 || C == 64) ? 0 : 2 * (slice / K::CC);
+    const bool own = K::JS == 1 || C == 32 || slice < K::CC;
+    float* Tg = T + (size_t)grp * K::JS * 16 * K::TS;
+    const int per_it = gridDim.x * K::TG, unit0 = blockIdx.x * K::TG + grp;
+    const int iters = (a.ntiles + per_it - 1) / per_it;
+    for (int it = 0; it < iters; ++it) {
+        const int tile = unit0 + it * per_it;
+        const bool valid = tile < a.ntiles;
+        int b = 0, p0 = 0;
+        if (valid) tile_of<C>(tile, P, b, p0);
+        const size_t base = (size_t)b * C * P + p0;
+        const float sb = (valid && a.sdp) ? a.sdp[b] : 1.f;
+        int wofs = 4 * q * (C + 4) + n;
+        asm volatile("" : "+v"(wofs));
+        floatx4 d[DN];
+        zero(d);
+        VT na[K::CC][4], fa[K::CC][4];       // n and df = s g in layout A (operands of the two products that make pre / dh)
+        if (valid) {
+            load_a<C>(a.nrm + base, P, na, n, q);
+            load_a<C>(a.g + base, P, fa, n, q);
+#pragma unroll
+            for (int cc = 0; cc < K::CC; ++cc)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fa[cc][s] *= sb;
+        }
+#pragma unroll
+        for (int nt = 0; nt < K::NTW; ++nt) {
+            floatx4 pre[K::TT], dh[K::TT];
+            if (valid) {
+                fc1_dp<C>(na, w1r[nt], pre);
+                fc1_dp<C>(fa, w2r[nt], dh);
+                // pre / dh [t][i]: hidden j0 + 16nt + n, pixel p0 + 4TT i + TT q + t
+#pragma unroll
+                for (int t = 0; t < K::TT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float z = pre[t][i] + b0v[nt];
+                        const float dz = dh[t][i] * gelu_grad_f(z);
+                        pre[t][i] = gelu_f(z);       // a = gelu(pre)
+                        dh[t][i] = dz;               // d loss / d pre
+                        sb0[nt] += dz;
+                    }
+                // weight gradients: the layout-B operands (n, df) are re-read per hidden tile, one 16-channel tile at a time (L1 / L2
+                // hits): holding them across the hidden tiles costs 32 CC registers and spills
+#pragma unroll
+                for (int ct = 0; ct < K::CC; ++ct) {
+                    const size_t o = base + (size_t)(16 * ct + n) * P + K::TT * q;
+                    asm volatile("" ::: "memory");
+                    VT nb[4], fb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        nb[i] = *reinterpret_cast<const VT*>(a.nrm + o + 4 * K::TT * i);
+                        fb[i] = *reinterpret_cast<const VT*>(a.g + o + 4 * K::TT * i) * sb;
+                        if (nt == 0) {
+#pragma unroll
+                            for (int t = 0; t < K::TT; ++t) sb2[ct] += fb[i][t];
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < K::TT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            mfma(acc2[ct][nt], fb[i][t], pre[t][i]);        // dW2[c][j] += df a
+                            mfma(acc0[ct][nt], dh[t][i], nb[i][t]);         // dW0[j][c] += dh n
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    VT v;
+#pragma unroll
+                    for (int t = 0; t < K::TT; ++t) v[t] = dh[t][i];
+                    *reinterpret_cast<VT*>(Tg + (size_t)(slice * 16 + n) * K::TS + 4 * K::TT * i + K::TT * q) = v;
+                }
+            }
+            if constexpr (K::JS == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+                __syncthreads();
+            }
+            if (valid && own) {
+#pragma unroll
+                for (int sl = 0; sl < K::JS; ++sl) {
+                    if (sl & 1) asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int row = sl * 16 + 4 * q + s;
+                        const DV av = *reinterpret_cast<const DV*>(Tg + (size_t)row * K::TS + poff + own_t0);
+                        const float bv = wl[(sl * K::SW + 16 * nt + s) * (C + 4) + 16 * own_ct + wofs];
+#pragma unroll
+                        for (int k = 0; k < DN; ++k) mfma(d[k], av[k], bv);
+                    }
+                }
+            }
+            if constexpr (K::JS == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                __syncthreads();
+            }
+        }
+        if (valid && own) {
+            drain(d);
+            const size_t o = base + (size_t)(16 * own_ct + n) * P + K::TT * q + own_t0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                DV v;
+#pragma unroll
+                for (int k = 0; k < DN; ++k) v[k] = d[k][i];
+                *reinterpret_cast<DV*>(a.dn + o + 4 * K::TT * i) = v;
+            }
+        }
+    }
+    // ---- epilogue: slabs of both weight gradients and the bias-gradient row of this workgroup
+#pragma unroll
+    for (int ct = 0; ct < K::CC; ++ct) drain(acc0[ct]), drain(acc2[ct]);
+#pragma unroll
+    for (int nt = 0; nt < K::NTW; ++nt) sb0[nt] += __shfl_xor(sb0[nt], 16), sb0[nt] += __shfl_xor(sb0[nt], 32);
+#pragma unroll
+    for (int ct = 0; ct < K::CC; ++ct) sb2[ct] += __shfl_xor(sb2[ct], 16), sb2[ct] += __shfl_xor(sb2[ct], 32);
+    __syncthreads();
+    constexpr int SL = C * K::HID, ROWF = K::HID + C;
+    float* s0 = a.slab_w0 + (size_t)blockIdx.x * SL;
+    float* s2 = a.slab_w2 + (size_t)blockIdx.x * SL;
+    float* rb = a.rows_b + (size_t)blockIdx.x * ROWF;
+    if constexpr (K::TG > 1) {
+        // the tile groups hold sums over different tiles: dW0 first, then dW2 and the bias sums, through the same LDS region
+        float* cg = T + (size_t)grp * (SL + ROWF);
+#pragma unroll
+        for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cg[(j0 + 16 * nt + 4 * q + i) * C + 16 * ct + n] = acc0[ct][nt][i];
+        if (q == 0) {
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt) cg[SL + j0 + 16 * nt + n] = sb0[nt];
+            if (slice == 0) {
+#pragma unroll
+                for (int ct = 0; ct < K::CC; ++ct) cg[SL + K::HID + 16 * ct + n] = sb2[ct];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < SL + ROWF; e += K::NTHR) {
+            float v = T[e];
+#pragma unroll
+            for (int g2 = 1; g2 < K::TG; ++g2) v += T[(size_t)g2 * (SL + ROWF) + e];
+            if (e < SL) s0[e] = v;
+            else rb[e - SL] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cg[(16 * ct + 4 * q + i) * K::HID + j0 + 16 * nt + n] = acc2[ct][nt][i];
+        __syncthreads();
+        for (int e = tid; e < SL; e += K::NTHR) {
+            float v = T[e];
+#pragma unroll
+            for (int g2 = 1; g2 < K::TG; ++g2) v += T[(size_t)g2 * (SL + ROWF) + e];
+            s2[e] = v;
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < K::CC; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s0[(j0 + 16 * nt + 4 * q + i) * C + 16 * ct + n] = acc0[ct][nt][i];
+                    s2[(16 * ct + 4 * q + i) * K::HID + j0 + 16 * nt + n] = acc2[ct][nt][i];
+                }
+        if (q == 0) {
+#pragma unroll
+            for (int nt = 0; nt < K::NTW; ++nt) rb[j0 + 16 * nt + n] = sb0[nt];
+            if (slice == 0) {
+#pragma unroll
+                for (int ct = 0; ct < K::CC; ++ct) rb[K::HID + 16 * ct + n] = sb2[ct];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ host side
 inline int rows_for(int iters, int gmax) {      // largest workgroup count <= gmax that splits `iters` iterations evenly
     if (iters <= gmax) return iters;
@@ -1082,6 +1452,60 @@ size_t bwd_ws_floats(int B, int P) {
     return (size_t)red2_rows(B, P) * 3 * C + (size_t)pl.R * 2 * Cfg<C>::HID + 4 * C;
 }
 
+
+template <int C>
+int tail_fwd_t(const float* nrm, const float* x, const float* w0, const float* b0, const float* w2, const float* b2, const float* sdp,
+               float* out, int B, int P, hipStream_t st) {
+    using K = Cfg<C>;
+    const Plan<C> pl(B, P);
+    const size_t lds = TailFwdLds<C>::BYTES;
+    KMU_MAX_LDS((tail_ffn_fwd_kernel<C>), lds);
+    hipLaunchKernelGGL((tail_ffn_fwd_kernel<C>), dim3(pl.G), dim3(K::NTHR), lds, st, nrm, x, w0, b0, w2, b2, sdp, out, P, pl.ntiles);
+    return kmu::launch_status("tail_ffn_fwd");
+}
+template <int C>
+int tail_bwd_t(TailBArgs a, int B, int P, hipStream_t st) {
+    using K = Cfg<C>;
+    const Plan<C> pl(B, P);
+    a.P = P, a.ntiles = pl.ntiles;
+    const size_t lds = TailBwdLds<C>::BYTES;
+    KMU_MAX_LDS((tail_ffn_bwd_kernel<C>), lds);
+    hipLaunchKernelGGL((tail_ffn_bwd_kernel<C>), dim3(pl.G), dim3(K::NTHR), lds, st, a);
+    return kmu::launch_status("tail_ffn_bwd");
+}
+
+}  // namespace
+
+// ---- EnhancedViMBlock's FFN tail (KM_UNetV3_SH.py:120-124, :147-150): out = x + s[b] (W2 gelu(W0 nrm + b0) + b2), nrm = TripleNorm(x)
+// computed by the caller (kmu_triple_norm_fwd).  Same shape support as kmu_ffn_fused_*; rows = kmu_ffn_fused_rows(B, C, P, 1).
+// bwd: dn = d loss / d nrm; slab_w0 [rows][4C][C], slab_w2 [rows][C][4C], rows_b [rows][4C + C] (db0 | db2): column sums = gradients.
+extern "C" int kmu_tail_ffn_fwd(const float* nrm, const float* x, const float* w0, const float* b0, const float* w2, const float* b2,
+                                const float* sdp, float* out, int B, int C, int P, kmu_stream_t stream) {
+    KMU_REQUIRE(nrm && x && w0 && b0 && w2 && b2 && out, "tail_ffn_fwd: null pointer");
+    KMU_REQUIRE(B > 0 && ffn_ok(C, 4 * C, P), "tail_ffn_fwd: C = %d (16 / 32 / 64) with 4C hidden channels and H*W = %d (multiple of 64) only", C, P);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 16: return tail_fwd_t<16>(nrm, x, w0, b0, w2, b2, sdp, out, B, P, st);
+        case 32: return tail_fwd_t<32>(nrm, x, w0, b0, w2, b2, sdp, out, B, P, st);
+        default: return tail_fwd_t<64>(nrm, x, w0, b0, w2, b2, sdp, out, B, P, st);
+    }
+}
+
+extern "C" int kmu_tail_ffn_bwd(const float* nrm, const float* g, const float* w0, const float* b0, const float* w2, const float* sdp,
+                                float* dn, float* slab_w0, float* slab_w2, float* rows_b, int B, int C, int P, kmu_stream_t stream) {
+    KMU_REQUIRE(nrm && g && w0 && b0 && w2 && dn && slab_w0 && slab_w2 && rows_b, "tail_ffn_bwd: null pointer");
+    KMU_REQUIRE(B > 0 && ffn_ok(C, 4 * C, P), "tail_ffn_bwd: C = %d (16 / 32 / 64) with 4C hidden channels and H*W = %d (multiple of 64) only", C, P);
+    TailBArgs a = {};
+    a.nrm = nrm, a.g = g, a.w0 = w0, a.b0 = b0, a.w2 = w2, a.sdp = sdp, a.dn = dn, a.slab_w0 = slab_w0, a.slab_w2 = slab_w2, a.rows_b = rows_b;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 16: return tail_bwd_t<16>(a, B, P, st);
+        case 32: return tail_bwd_t<32>(a, B, P, st);
+        default: return tail_bwd_t<64>(a, B, P, st);
+    }
+}
+
+namespace {
 }  // namespace
 
 extern "C" int kmu_ffn_fused_supported(int C, int hid, int P) { return ffn_ok(C, hid, P) ? 1 : 0; }

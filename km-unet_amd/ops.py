@@ -1093,24 +1093,41 @@ class VimTailFn(torch.autograd.Function):
         sc = None if s is None else _f32c(s, "s").view(B)
         st = _stream()
         n, stats = _k_tn_fwd(lib, x, *p, eps_gn, eps_ln)
-        h = torch.empty(B, hid, H, W, device=x.device, dtype=torch.float32)
-        _lib.check(_call(("pwconv_fwd", (B, C, hid, P)), lib.kmu_pwconv_fwd, _ptr(n), _ptr(w0c), _ptr(b0c), _ptr(h), B, C, hid, P, 0, st),
-                   "kmu_pwconv_fwd")
         out = torch.empty_like(x)
-        _lib.check(_call(("pwconv_fwd_res", (B, hid, C, P)), lib.kmu_pwconv_fwd_res, _ptr(h), _ptr(w2c), _ptr(b2c), _ptr(x), _ptr(sc),
-                         _ptr(out), B, hid, C, P, 1, st), "kmu_pwconv_fwd_res")
-        ctx.save_for_backward(x, p[0], p[2], p[4], stats, n, h, w0c, w2c, sc)
+        fused = FFN_FUSED and hid == 4 * C and bool(lib.kmu_ffn_fused_supported(C, hid, P))
+        if fused:       # fc1 -> GELU -> fc2 -> DropPath factor -> residual in ONE launch, the 4C-wide hidden tensor stays in registers
+            _lib.check(_call(("tail_ffn_fwd", (B, C, P)), lib.kmu_tail_ffn_fwd, _ptr(n), _ptr(x), _ptr(w0c), _ptr(b0c), _ptr(w2c), _ptr(b2c),
+                             _ptr(sc), _ptr(out), B, C, P, st), "kmu_tail_ffn_fwd")
+            h = None
+        else:
+            h = torch.empty(B, hid, H, W, device=x.device, dtype=torch.float32)
+            _lib.check(_call(("pwconv_fwd", (B, C, hid, P)), lib.kmu_pwconv_fwd, _ptr(n), _ptr(w0c), _ptr(b0c), _ptr(h), B, C, hid, P, 0, st),
+                       "kmu_pwconv_fwd")
+            _lib.check(_call(("pwconv_fwd_res", (B, hid, C, P)), lib.kmu_pwconv_fwd_res, _ptr(h), _ptr(w2c), _ptr(b2c), _ptr(x), _ptr(sc),
+                             _ptr(out), B, hid, C, P, 1, st), "kmu_pwconv_fwd_res")
+        ctx.save_for_backward(x, p[0], p[2], p[4], stats, n, h, w0c, w2c, sc, b0c)
         ctx.cfg = (float(eps_ln), tuple(w0.shape), tuple(w2.shape))
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, gh, gw, gc, stats, n, h, w0c, w2c, sc = ctx.saved_tensors
+        x, gh, gw, gc, stats, n, h, w0c, w2c, sc, b0c = ctx.saved_tensors
         eps_ln, s0, s2 = ctx.cfg
         g = _f32c(g, "grad")
         B, C, H, W = x.shape
         P, hid, dev, st = H * W, w0c.shape[0], x.device, _stream()
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        dw0, db0, dw2, db2, dG, dB, dC = mk(hid, C), mk(hid), mk(C, hid), mk(C), mk(C), mk(C), mk(C)
+        if h is None:   # recompute form: one launch gives dn and the partials of all four parameter gradients
+            rows = lib.kmu_ffn_fused_rows(B, C, P, 1)
+            dn, slab0, slab2, rows_b = torch.empty_like(n), mk(rows, hid * C), mk(rows, C * hid), mk(rows, hid + C)
+            _lib.check(_call(("tail_ffn_bwd", (B, C, P)), lib.kmu_tail_ffn_bwd, _ptr(n), _ptr(g), _ptr(w0c), _ptr(b0c), _ptr(w2c), _ptr(sc),
+                             _ptr(dn), _ptr(slab0), _ptr(slab2), _ptr(rows_b), B, C, P, st), "kmu_tail_ffn_bwd")
+            dx, dgp, dbp, dcp = _k_tn_bwd(lib, x, dn, gh, gw, gc, stats, g, eps_ln)
+            dbb = mk(hid + C)
+            _wgrad(lambda: colsum(slab0, slab2, rows_b, dgp, dbp, dcp, outs=[dw0.view(-1), dw2.view(-1), dbb, dG, dB, dC]), ctx.defer_wgrad)
+            return dx, dG, dB, dG, dB, dC, dB, None, None, dw0.view(s0), dbb[:hid], dw2.view(s2), dbb[hid:], None
         dh = torch.empty_like(h)                    # d loss / d ffn0 output = s (W2^T g) GELU'(h)
         _lib.check(_call(("pwconv_bwd_input_s", (B, hid, C, P)), lib.kmu_pwconv_bwd_input_s, _ptr(g), _ptr(w2c), _ptr(h), _ptr(sc), _ptr(dh),
                          B, hid, C, P, 1, st), "kmu_pwconv_bwd_input_s")
@@ -1118,8 +1135,6 @@ class VimTailFn(torch.autograd.Function):
         _lib.check(_call(("pwconv_bwd_input", (B, C, hid, P)), lib.kmu_pwconv_bwd_input, _ptr(dh), _ptr(w0c), None, _ptr(dn), B, C, hid, P, 0,
                          st), "kmu_pwconv_bwd_input")
         dx, dgp, dbp, dcp = _k_tn_bwd(lib, x, dn, gh, gw, gc, stats, g, eps_ln)
-        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        dw0, db0, dw2, db2, dG, dB, dC = mk(hid, C), mk(hid), mk(C, hid), mk(C), mk(C), mk(C), mk(C)
 
         def job():
             sg = g if sc is None else g * sc.view(B, 1, 1, 1)
