@@ -1202,8 +1202,9 @@ __global__ __launch_bounds__(Cfg<C>::NTHR) void tail_ffn_bwd_kernel(TailBArgs a)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float z = pre[t][i] + b0v[nt];
-                        const float dz = dh[t][i] * gelu_grad_f(z);
-                        pre[t][i] = gelu_f(z);       // a = gelu(pre)
+                        const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));     // one erf serves gelu and gelu'
+                        const float dz = dh[t][i] * fmaf(z * 0.39894228040143268f, __expf(-0.5f * z * z), cdf);
+                        pre[t][i] = z * cdf;         // a = gelu(pre)
                         dh[t][i] = dz;               // d loss / d pre
                         sb0[nt] += dz;
                     }

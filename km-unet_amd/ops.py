@@ -1094,7 +1094,7 @@ class VimTailFn(torch.autograd.Function):
         st = _stream()
         n, stats = _k_tn_fwd(lib, x, *p, eps_gn, eps_ln)
         out = torch.empty_like(x)
-        fused = FFN_FUSED and hid == 4 * C and bool(lib.kmu_ffn_fused_supported(C, hid, P))
+        fused = TAIL_FUSED and hid == 4 * C and bool(lib.kmu_ffn_fused_supported(C, hid, P))
         if fused:       # fc1 -> GELU -> fc2 -> DropPath factor -> residual in ONE launch, the 4C-wide hidden tensor stays in registers
             _lib.check(_call(("tail_ffn_fwd", (B, C, P)), lib.kmu_tail_ffn_fwd, _ptr(n), _ptr(x), _ptr(w0c), _ptr(b0c), _ptr(w2c), _ptr(b2c),
                              _ptr(sc), _ptr(out), B, C, P, st), "kmu_tail_ffn_fwd")
@@ -1410,7 +1410,7 @@ class DwBnBlendFn(torch.autograd.Function):
         training, wshape = ctx.cfg
         B, C, H, W = x.shape
         st = _stream()
-        if W % 4 == 0 and C <= 4096:
+        if DWBN_FUSED and W % 4 == 0 and C <= 4096:
             # BatchNorm's backward folded into the transposed stencil: reduce (partials), then dx = dwconv^T(dt) + (1 - a) g with dt
             # formed on the fly from (g, t) -- no dt / dxb tensors, one launch less on the activation-gradient chain
             g = _f32c(g, "grad")
@@ -1493,6 +1493,8 @@ class FfnBlendFn(torch.autograd.Function):
 # The FFN stage as recompute kernels (csrc/ffn_fused.hip): nothing 4C wide is stored.  KMU_FFN_FUSED=0 keeps the pointwise-conv +
 # BatchNorm kernels (FfnBlendFn), which also serve the shapes the fused kernels do not cover (C not in {16, 32, 64}, H*W % 64 != 0).
 FFN_FUSED = os.environ.get("KMU_FFN_FUSED", "1") == "1"
+TAIL_FUSED = os.environ.get("KMU_TAIL_FUSED", "1") == "1"      # EnhancedViMBlock's tail FFN as one recompute launch each way
+DWBN_FUSED = os.environ.get("KMU_DWBN_FUSED", "1") == "1"      # dwconv stage backward: BatchNorm folded into the transposed stencil
 _FFN_STAGES_F = ("ffn_fwd_stats", "ffn_fwd_main", "ffn_fwd_apply")
 _FFN_STAGES_B = ("ffn_bwd_red", "ffn_bwd_mid", "ffn_bwd_in")
 
