@@ -225,79 +225,146 @@ __global__ __launch_bounds__(256) void dysample_bwd_tiled_kernel(const float* __
     }
 }
 
-// Channel-major variant for cg = C/4 = 16 (KM-UNet: C = 64): lane = (channel c = tid & 15, pixel slot = tid >> 4).  The 64
-// lanes of a wave then scatter into 16 different channel planes of the LDS window (plane stride 401 words => the 16
-// lanes of a DPP row hit 16 distinct banks) instead of 64 neighbouring pixels of ONE plane, whose 2x-upsampling footprints
-// collide on the same few addresses and serialise the ds_add_f32; the per-pixel offset gradient (a sum over the group's
-// channels) is a 16-lane row reduction.  Same arithmetic per (pixel, channel) as the tiled kernel above.
+// Gather-form backward for cg = 16 (KM-UNet: C = 64) -- round 3, replaces the LDS / global float-atomic scatter on the model's path.
+// One workgroup = an 8 x 8 tile of INPUT pixels of one (b, group).  An output pixel (2h+i, 2w+j) samples around its source (h, w); while
+// its footprint stays within R = 2 pixels of the source ("near": always at the model's offset scale, init std 1e-3, and up to
+// |offset| < 2 px) every contribution to a tile cell comes from the (8 + 2R)^2 x 4 = 576 candidate outputs around the tile.  Their
+// sample coordinates and their dy values (16 channels) are staged in LDS once; then every (cell, channel) SUMS its candidates in a
+// fixed order -- no atomics, bit-reproducible, and no serial gather -> atomic chain (177 -> ~30 us at 64 x 64).  A "far" sample
+// (footprint beyond R; needs |0.25 conv_out + init_pos| >= 2 px) is scattered by the tile that owns its source with global atomics,
+// as before: rare, and the only order-dependent sums left in this file.  dx must be zero-initialised (the caller does): the tile's
+// cell sums are ADDED to it, so that far samples from other tiles can land in the same cells.
+constexpr int GT = 8, GR = 2, GS = GT + 2 * GR, GP = GS + 1, GPL = 4 * GS * GP;   // tile, radius, candidate sources per edge, row pitch, plane
 
-template <int TB>   // output tile edge: 32 (window 20x20) or 16 (window 12x12: 4x the workgroups, for the small levels)
-__global__ __launch_bounds__(256) void dysample_bwd_chan_kernel(const float* __restrict__ x, const float* __restrict__ conv_out,
-                                                                const float* __restrict__ init_pos, const float* __restrict__ dy,
-                                                                float* __restrict__ dx, float* __restrict__ d_conv_out, int C, int H,
-                                                                int W, int tilesX) {
-    constexpr int WN = TB / 2 + 4, WS = WN * WN + 1;   // window edge; plane stride (odd => the 16 channel lanes hit 16 banks)
-    extern __shared__ __attribute__((aligned(16))) float win[];  // [16][WS]
-    const int OH = 2 * H, OW = 2 * W;
+__global__ __launch_bounds__(256) void dysample_bwd_gather_kernel(const float* __restrict__ x, const float* __restrict__ conv_out,
+                                                                  const float* __restrict__ init_pos, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, float* __restrict__ d_conv_out, int C, int H,
+                                                                  int W, int tilesX) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* cx0 = reinterpret_cast<int*>(lds);            // [ij][sy][GP]: x0, or -1 for "not a near candidate"
+    int* cy0 = cx0 + GPL;
+    float* cfx = reinterpret_cast<float*>(cy0 + GPL);
+    float* cfy = cfx + GPL;
+    int* cfl = reinterpret_cast<int*>(cfy + GPL);      // bit 0: in_x, bit 1: in_y, bit 2: far sample
+    float* gos = reinterpret_cast<float*>(cfl + GPL);  // [16][GPL]
+    float* xw = gos + 16 * GPL;                        // [16][GS * GP]: x on the candidate-source window (zero outside the image)
+    int* rad = reinterpret_cast<int*>(xw + 16 * GS * GP);   // largest |footprint - source| among the near candidates (<= GR)
     constexpr int cg = 16;
+    const int OH = 2 * H, OW = 2 * W;
     const int b = blockIdx.z, g = blockIdx.y;
-    const int oy0 = (blockIdx.x / tilesX) * TB, ox0 = (blockIdx.x % tilesX) * TB;
-    const int wy0 = oy0 / 2 - 2, wx0 = ox0 / 2 - 2;
-    for (int e = threadIdx.x; e < cg * WS; e += 256) win[e] = 0.f;
-    __syncthreads();
+    const int ty0 = (blockIdx.x / tilesX) * GT, tx0 = (blockIdx.x % tilesX) * GT;
     const size_t hw = (size_t)H * W;
-    const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const size_t cbase = ((size_t)b * C + (size_t)g * cg + c) * hw;
-    const float* xc = x + cbase;
-    float* dxc = dx + cbase;
-    float* wc = win + c * WS;
-    const float* dyc = dy + ((size_t)b * C + (size_t)g * cg + c) * OH * OW;
-    for (int it = 0; it < TB * TB / 16; ++it) {
-        const int p = it * 16 + slot, oy = oy0 + p / TB, ox = ox0 + p % TB;
-        const bool live = oy < OH && ox < OW;
-        float gpx = 0.f, gpy = 0.f;
-        Samp s;
-        if (live) {
-            s = dys_coords(conv_out, init_pos, b, g, oy, ox, H, W);
-            const float w00 = (1.f - s.fx) * (1.f - s.fy), w01 = s.fx * (1.f - s.fy), w10 = (1.f - s.fx) * s.fy, w11 = s.fx * s.fy;
-            const int o00 = s.y0 * W + s.x0, o01 = s.y0 * W + s.x1, o10 = s.y1 * W + s.x0, o11 = s.y1 * W + s.x1;
-            const float go = dyc[(size_t)oy * OW + ox];
-            const float v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
-            if (s.y0 >= wy0 && s.y1 < wy0 + WN && s.x0 >= wx0 && s.x1 < wx0 + WN) {
-                const int ly0 = (s.y0 - wy0) * WN, ly1 = (s.y1 - wy0) * WN, lx0 = s.x0 - wx0, lx1 = s.x1 - wx0;
-                atomicAdd(wc + ly0 + lx0, go * w00);
-                atomicAdd(wc + ly0 + lx1, go * w01);
-                atomicAdd(wc + ly1 + lx0, go * w10);
-                atomicAdd(wc + ly1 + lx1, go * w11);
-            } else {
-                atomicAdd(dxc + o00, go * w00);
-                atomicAdd(dxc + o01, go * w01);
-                atomicAdd(dxc + o10, go * w10);
-                atomicAdd(dxc + o11, go * w11);
-            }
-            gpx = go * ((v01 - v00) * (1.f - s.fy) + (v11 - v10) * s.fy);
-            gpy = go * ((v10 - v00) * (1.f - s.fx) + (v11 - v01) * s.fx);
+    const float* dyg = dy + ((size_t)b * C + (size_t)g * cg) * OH * OW;
+    // ---- phase 0: coordinates of the candidate outputs, their dy values, and x on the window
+    if (threadIdx.x == 0) *rad = 0;
+    __syncthreads();
+    int myrad = 0;
+    for (int e = threadIdx.x; e < 4 * GS * GS; e += 256) {
+        const int ij = e / (GS * GS), r = e - ij * GS * GS, sy = r / GS, sx = r - sy * GS;
+        const int h = ty0 - GR + sy, w = tx0 - GR + sx, idx = ij * GS * GP + sy * GP + sx;
+        int x0 = -1, y0 = 0, fl = 0;
+        float fx = 0.f, fy = 0.f;
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const Samp s = dys_coords(conv_out, init_pos, b, g, 2 * h + (ij >> 1), 2 * w + (ij & 1), H, W);
+            const bool near = s.x0 >= w - GR && s.x1 <= w + GR && s.y0 >= h - GR && s.y1 <= h + GR;
+            fl = (s.in_x ? 1 : 0) | (s.in_y ? 2 : 0) | (near ? 0 : 4);
+            x0 = s.x0, y0 = s.y0, fx = s.fx, fy = s.fy;
+            if (near) myrad = max(myrad, max(max(w - s.x0, s.x1 - w), max(h - s.y0, s.y1 - h)));
         }
-        // sum over the 16 channel lanes of this pixel (one DPP row): row_shr 1, 2, 4, 8 leaves the total in lane 15
-        gpx += kmu::dpp_mov<0x111, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x111, 0xf>(0.f, gpy);
-        gpx += kmu::dpp_mov<0x112, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x112, 0xf>(0.f, gpy);
-        gpx += kmu::dpp_mov<0x114, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x114, 0xf>(0.f, gpy);
-        gpx += kmu::dpp_mov<0x118, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x118, 0xf>(0.f, gpy);
-        if (live && c == 15) {
-            const int h = oy >> 1, i = oy & 1, w = ox >> 1, j = ox & 1;
-            const int chx = g * 4 + i * 2 + j, chy = 16 + chx;
-            const size_t pix = (size_t)h * W + w;
-            d_conv_out[((size_t)b * 32 + chx) * hw + pix] = s.in_x ? 0.25f * gpx : 0.f;
-            d_conv_out[((size_t)b * 32 + chy) * hw + pix] = s.in_y ? 0.25f * gpy : 0.f;
+        cx0[idx] = x0, cy0[idx] = y0, cfx[idx] = fx, cfy[idx] = fy, cfl[idx] = fl;
+    }
+    for (int e = threadIdx.x; e < cg * 2 * GS * GS; e += 256) {      // two horizontally adjacent outputs (j = 0, 1) per item: 8-byte loads
+        const int c = e / (2 * GS * GS), r = e - c * 2 * GS * GS, i = r / (GS * GS), r2 = r - i * GS * GS, sy = r2 / GS, sx = r2 - sy * GS;
+        const int h = ty0 - GR + sy, w = tx0 - GR + sx;
+        float v0 = 0.f, v1 = 0.f;
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const float* p = dyg + ((size_t)c * OH + 2 * h + i) * OW + 2 * w;
+            v0 = p[0], v1 = p[1];
         }
+        gos[c * GPL + (2 * i) * GS * GP + sy * GP + sx] = v0;
+        gos[c * GPL + (2 * i + 1) * GS * GP + sy * GP + sx] = v1;
+    }
+    if (myrad) atomicMax(rad, myrad);
+    for (int e = threadIdx.x; e < cg * GS * GS; e += 256) {
+        const int c = e / (GS * GS), r = e - c * GS * GS, sy = r / GS, sx = r - sy * GS;
+        const int h = ty0 - GR + sy, w = tx0 - GR + sx;
+        xw[c * GS * GP + sy * GP + sx] = (h >= 0 && h < H && w >= 0 && w < W) ? x[((size_t)b * C + (size_t)g * cg + c) * hw + (size_t)h * W + w] : 0.f;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < cg * WN * WN; e += 256) {
-        const int cc = e / (WN * WN), r = e % (WN * WN);
-        const float v = win[cc * WS + r];
-        if (v == 0.f) continue;
-        const int yy = wy0 + r / WN, xx = wx0 + r % WN;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(dx + ((size_t)b * C + (size_t)g * cg + cc) * hw + (size_t)yy * W + xx, v);
+    // ---- phase 1: offset gradient of the tile's own 16 x 16 outputs (16 channel lanes per output: a DPP row sum), far samples scattered
+    {
+        const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
+        const size_t cbase = ((size_t)b * C + (size_t)g * cg + c) * hw;
+        const float* xc = x + cbase;
+        float* dxc = dx + cbase;
+        for (int it = 0; it < 4 * GT * GT / 16; ++it) {
+            const int p = it * 16 + slot, ly = p / (2 * GT), lx = p % (2 * GT);      // output position inside the tile's 16 x 16 outputs
+            const int h = ty0 + (ly >> 1), w = tx0 + (lx >> 1), ij = (ly & 1) * 2 + (lx & 1);
+            const bool live = h < H && w < W;
+            float gpx = 0.f, gpy = 0.f;
+            int fl = 0;
+            if (live) {
+                const int idx = ij * GS * GP + ((ly >> 1) + GR) * GP + (lx >> 1) + GR;
+                const int x0 = cx0[idx], y0 = cy0[idx];
+                const float fx = cfx[idx], fy = cfy[idx], go = gos[c * GPL + idx];
+                fl = cfl[idx];
+                const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+                const int o00 = y0 * W + x0, o01 = y0 * W + x1, o10 = y1 * W + x0, o11 = y1 * W + x1;
+                float v00, v01, v10, v11;
+                if (fl & 4) {
+                    v00 = xc[o00], v01 = xc[o01], v10 = xc[o10], v11 = xc[o11];
+                } else {             // near sample: its four corners lie inside the staged window
+                    const float* xl = xw + c * GS * GP;
+                    const int ly0 = (y0 - (ty0 - GR)) * GP, ly1 = (y1 - (ty0 - GR)) * GP, lx0 = x0 - (tx0 - GR), lx1 = x1 - (tx0 - GR);
+                    v00 = xl[ly0 + lx0], v01 = xl[ly0 + lx1], v10 = xl[ly1 + lx0], v11 = xl[ly1 + lx1];
+                }
+                if (fl & 4) {        // far sample: the gather below skips it
+                    atomicAdd(dxc + o00, go * ((1.f - fx) * (1.f - fy)));
+                    atomicAdd(dxc + o01, go * (fx * (1.f - fy)));
+                    atomicAdd(dxc + o10, go * ((1.f - fx) * fy));
+                    atomicAdd(dxc + o11, go * (fx * fy));
+                }
+                gpx = go * ((v01 - v00) * (1.f - fy) + (v11 - v10) * fy);
+                gpy = go * ((v10 - v00) * (1.f - fx) + (v11 - v01) * fx);
+            }
+            gpx += kmu::dpp_mov<0x111, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x111, 0xf>(0.f, gpy);
+            gpx += kmu::dpp_mov<0x112, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x112, 0xf>(0.f, gpy);
+            gpx += kmu::dpp_mov<0x114, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x114, 0xf>(0.f, gpy);
+            gpx += kmu::dpp_mov<0x118, 0xf>(0.f, gpx), gpy += kmu::dpp_mov<0x118, 0xf>(0.f, gpy);
+            if (live && c == 15) {
+                const int chx = g * 4 + ij, chy = 16 + chx;
+                const size_t pix = (size_t)h * W + w;
+                d_conv_out[((size_t)b * 32 + chx) * hw + pix] = (fl & 1) ? 0.25f * gpx : 0.f;
+                d_conv_out[((size_t)b * 32 + chy) * hw + pix] = (fl & 2) ? 0.25f * gpy : 0.f;
+            }
+        }
+    }
+    // ---- phase 2: dx of the tile's cells: (cell = lane, 4 channels per wave) sums its candidates in a fixed order
+    {
+        const int cell = threadIdx.x & 63, cq = threadIdx.x >> 6, wy = cell >> 3, wx = cell & 7;
+        const int yy = ty0 + wy, xx = tx0 + wx;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* g4 = gos + (size_t)(4 * cq) * GPL;
+        const int rr = *rad;             // candidates beyond the largest near footprint of this tile cannot contribute: usually 1, not GR
+        for (int dh = GR - rr; dh <= GR + rr; ++dh)
+            for (int dw = GR - rr; dw <= GR + rr; ++dw)
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) {
+                    const int idx = ij * GS * GP + (wy + dh) * GP + wx + dw;       // source (yy + dh - R, xx + dw - R)
+                    const int x0 = cx0[idx], y0 = cy0[idx];
+                    const float fx = cfx[idx], fy = cfy[idx];
+                    const bool use = x0 >= 0 && !(cfl[idx] & 4);
+                    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+                    const float wxp = (x0 == xx ? 1.f - fx : 0.f) + (x1 == xx ? fx : 0.f);
+                    const float wyp = (y0 == yy ? 1.f - fy : 0.f) + (y1 == yy ? fy : 0.f);
+                    const float wgt = use ? wxp * wyp : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] += g4[k * GPL + idx] * wgt;
+                }
+        if (yy < H && xx < W) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(dx + ((size_t)b * C + (size_t)g * cg + 4 * cq + k) * hw + (size_t)yy * W + xx, acc[k]);
+        }
     }
 }
 
@@ -325,13 +392,11 @@ extern "C" int kmu_dysample_lp_bwd(const float* x, const float* conv_out, const 
     KMU_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "dysample_lp_bwd: bad dims");
     const size_t lds = (size_t)(C / 4) * BWIN * BWIN * sizeof(float);
     if (C == 64 && B <= 65535) {
-        // 16x16 output tiles (12x12 input window): the per-workgroup loop is a serial chain of gathers and LDS atomics, so
-        // more, shorter workgroups win at every level -- measured (B=8) against 32x32 tiles: 16x16 input 94 -> 28 us,
-        // 32x32 94 -> 53 us, 64x64 183 -> 177 us
-        constexpr int tb = 16;
-        const int tilesX = kmu::cdiv(2 * W, tb), tilesY = kmu::cdiv(2 * H, tb);
-        const size_t ldsc = (size_t)16 * ((tb / 2 + 4) * (tb / 2 + 4) + 1) * sizeof(float);
-        hipLaunchKernelGGL(dysample_bwd_chan_kernel<tb>, dim3(tilesX * tilesY, 4, B), dim3(256), ldsc, (hipStream_t)stream, x, conv_out,
+        // gather form (no float atomics for samples within 2 pixels of their source): see dysample_bwd_gather_kernel
+        const int tilesX = kmu::cdiv(W, GT), tilesY = kmu::cdiv(H, GT);
+        const size_t ldsg = ((size_t)(5 + 16) * GPL + 16 * GS * GP + 4) * sizeof(float);
+        KMU_MAX_LDS(dysample_bwd_gather_kernel, ldsg);
+        hipLaunchKernelGGL(dysample_bwd_gather_kernel, dim3(tilesX * tilesY, 4, B), dim3(256), ldsg, (hipStream_t)stream, x, conv_out,
                            init_pos, dy, dx, d_conv_out, C, H, W, tilesX);
         return kmu::launch_status("dysample_lp_bwd");
     }

@@ -343,6 +343,46 @@ def test_k3_golden(name):
     assert torch.equal(ix_o, g["ix0"]) and torch.equal(iy_o, g["iy0"])
 
 
+
+@pytest.mark.parametrize("B,H,W,std", [(2, 32, 32, 0.001), (2, 32, 32, 0.5), (1, 20, 28, 1.0), (1, 16, 16, 6.0), (8, 64, 64, 0.3)])
+def test_k3_backward_gather_vs_oracle(B, H, W, std):
+    """DySample backward in gather form (csrc/dysample.hip::dysample_bwd_gather_kernel, C = 64) against the oracle's autograd
+    (DySample_md.py:49-68 through F.grid_sample on the CPU): dx, d offset-conv weight / bias.  std scales the offset conv: 0.001 is
+    the model's init (every sample near its source), 6.0 sends most samples more than 2 pixels away (the far-sample scatter path),
+    and ragged sizes (20 x 28) leave partial tiles.  Without far samples two runs are bit-identical."""
+    import torch.nn.functional as F
+    from oracle import dysample as od
+    ops = _ops()
+    gen = torch.Generator().manual_seed(5 + H)
+    x = torch.randn(B, 64, H, W, generator=gen)
+    w = torch.randn(32, 64, 1, 1, generator=gen) * std / 8
+    bo = torch.randn(32, generator=gen) * std
+    ipos = od.init_pos()
+    gy = torch.randn(B, 64, 2 * H, 2 * W, generator=gen)
+    xo, wo, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bo.clone().requires_grad_(True)
+    od.dysample_lp(xo, wo, bb, ipos).backward(gy)
+
+    def run():
+        xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, bo))
+        conv = F.conv2d(xd, wd, bd)
+        conv.retain_grad()
+        y = ops.dysample_lp(xd, conv, ipos.to(DEV))
+        y.backward(gy.to(DEV))
+        return xd.grad, wd.grad, bd.grad, conv.grad
+    dx, dw, db, dconv = run()
+    _report("k3 bwd gather %s" % ((B, H, W, std),), dx=rel_err(dx, xo.grad), dw=rel_err(dw, wo.grad), db=rel_err(db, bb.grad))
+    if std <= 0.5:      # the kernel's own outputs (the offset conv's weight gradient is ATen's, through x.grad's second addend too)
+        dconv2 = run()[3]
+        assert torch.equal(dconv, dconv2)
+        xd = x.to(DEV).requires_grad_(True)
+        cv = F.conv2d(x, w, bo).to(DEV)
+        outs = []
+        for _ in range(2):
+            xd.grad = None
+            ops.dysample_lp(xd, cv, ipos.to(DEV)).backward(gy.to(DEV))
+            outs.append(xd.grad.clone())
+        assert torch.equal(outs[0], outs[1])
+
 @pytest.mark.parametrize("B,H,W,std", [(8, 64, 64, 0.5), (2, 60, 60, 1.0), (1, 15, 30, 2.0), (4, 16, 16, 0.001),
                                        (1, 128, 128, 0.5), (1, 240, 240, 1.0), (1, 120, 120, 3.0)])   # configs[3] / [4] levels
 def test_k3_indices_bit_exact_large(B, H, W, std):
