@@ -264,8 +264,21 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(data)
+    host_dt = time.perf_counter() - t0      # host time to ISSUE the steps (graph launches return before the device is done)
     sync()
     dt = time.perf_counter() - t0
+    # one step from an idle device: how long the host is held by the launch itself (a graph launch that returned only when the
+    # device was done would make the step host-bound)
+    lone = []
+    for _ in range(5):
+        sync()
+        ta = time.perf_counter()
+        step(data)
+        tb = time.perf_counter()
+        torch.cuda.synchronize()
+        lone.append((tb - ta, time.perf_counter() - ta))
+    lone.sort()
+    host_launch_ms, lone_step_ms = lone[2][0] * 1e3, sorted(t[1] for t in lone)[2] * 1e3
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -287,6 +300,8 @@ def main():
                                       "B=%d per GPU, T=%d, %dx%d -- BASELINE.json configs[1]" % (T - 5, args.loss, B, T, H, H),
                           "global_batch": world * B, "frames_per_sample": T, "parallelism": "dp%d" % world},
                "loss_first": loss_ref, "loss": final_loss, "launch_mode": "eager" if args.no_graph else "hipGraph replay",
+               "host_issue_ms_per_step": round(host_dt / args.steps * 1e3, 3), "host_launch_ms": round(host_launch_ms, 3),
+               "lone_step_ms": round(lone_step_ms, 3),
                "collective": ("%s all-reduce (average) of %d floats per step over %d rank(s), world %d" % (
                    backend, eager.dp.bucket.numel(), dist.get_world_size(), world)) if eager.dp.collective else "none (1 rank)"}
 

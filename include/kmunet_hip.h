@@ -551,6 +551,32 @@ int kmu_hsmssd_bwd_stage_x3_g(const float* x, const float* dy, const float* dh, 
                               float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
                               float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups,
                               kmu_stream_t stream);
+/* ------------------------------------------------------------------------------------
+ * Weight packs once per training step (round 3).  The split-bf16 kernels read their weights from fragment-ordered (hi, lo) packs;
+ * until now every forward and every backward call packed its own (63 launches per step, each the head of a dependent chain).
+ * A caller that knows the step boundary (km_unet_amd.ops.PackCache, used by train.TrainStep) keeps one persistent pack buffer per
+ * weight, lists them in a job table (64-byte records built on the HOST by kmu_conv_pack_job / kmu_hsm_pack_job, then copied to
+ * device memory once) and re-packs ALL of them with one launch per table at the head of the step; the consumers below take the pack
+ * as an argument.  Same packs as kmu_kan_pack_weights_x3 / kmu_kan_pack_weights_dgrad_x3 / kmu_conv2d_pack_weights_x3 and the pack
+ * stage of kmu_hsmssd_*_stage_x3 (KANConv2Dlayers.py:15-37, efficient_vim_init.py:39-45: pure re-layouts of the parameters).
+ * which: 0 KAN forward, 1 KAN input gradient, 2 plain conv forward, 3 plain conv input gradient (w1, w2 NULL for 2 and 3). */
+size_t kmu_pack_job_bytes(void);
+int kmu_conv_pack_job(void* host_table, int index, int which, const float* w0, const float* w1, const float* w2, void* wp, int Cin,
+                      int Cout, int ksize);
+int kmu_conv_pack_multi(const void* device_table, int njobs, kmu_stream_t stream);
+size_t kmu_hsmssd_pack_elems(int C, int groups);      /* bf16 elements */
+int kmu_hsmssd_pack_x3(const float* w_bcdt, const float* w_dw, void* wpk, int C, int groups, kmu_stream_t stream);
+int kmu_hsm_pack_job(void* host_table, int index, const float* w_bcdt, const float* w_dw, void* wpk, int C, int groups);
+int kmu_hsm_pack_multi(const void* device_table, int njobs, kmu_stream_t stream);
+/* kmu_hsmssd_{fwd,bwd}_stage_x3_g with the pack handed in (wpk NULL: pack inside stage 0 as before) */
+int kmu_hsmssd_fwd_stage_x3_pk(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
+                               const float* D, float* y, float* h, float* state, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,
+                               int stage, int groups, const void* wpk, kmu_stream_t stream);
+int kmu_hsmssd_bwd_stage_x3_pk(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw,
+                               const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
+                               float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
+                               float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups,
+                               const void* wpk, kmu_stream_t stream);
 int kmu_gate_mlp_fwd_g(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, float* z1, float* g, int B,
                        int I, int H, int O, int act1, int act2, int groups, kmu_stream_t stream);
 int kmu_gate_mlp_bwd_g(const float* p, const float* w1, const float* w2, const float* z1, const float* g, const float* dg, float* dp,

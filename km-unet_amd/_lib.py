@@ -118,6 +118,15 @@ SIGNATURES = {
     "kmu_hsmssd_fwd_stage_x3_g": (_I, [_P] * 10 + [_Z] + [_I] * 6 + [_P]),
     "kmu_hsmssd_bwd_ws_bytes_x3_g": (_Z, [_I] * 5),
     "kmu_hsmssd_bwd_stage_x3_g": (_I, [_P] * 16 + [_Z] + [_I] * 6 + [_P]),
+    "kmu_pack_job_bytes": (_Z, []),
+    "kmu_conv_pack_job": (_I, [_P, _I, _I] + [_P] * 4 + [_I] * 3),
+    "kmu_conv_pack_multi": (_I, [_P, _I, _P]),
+    "kmu_hsmssd_pack_elems": (_Z, [_I, _I]),
+    "kmu_hsmssd_pack_x3": (_I, [_P] * 3 + [_I, _I, _P]),
+    "kmu_hsm_pack_job": (_I, [_P, _I] + [_P] * 3 + [_I, _I]),
+    "kmu_hsm_pack_multi": (_I, [_P, _I, _P]),
+    "kmu_hsmssd_fwd_stage_x3_pk": (_I, [_P] * 10 + [_Z] + [_I] * 6 + [_P, _P]),
+    "kmu_hsmssd_bwd_stage_x3_pk": (_I, [_P] * 16 + [_Z] + [_I] * 6 + [_P, _P]),
     "kmu_gate_mlp_fwd_g": (_I, [_P] * 7 + [_I] * 7 + [_P]),
     "kmu_gate_mlp_bwd_g": (_I, [_P] * 11 + [_I] * 7 + [_P]),
     "kmu_mix3_fwd_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),

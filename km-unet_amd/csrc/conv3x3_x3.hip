@@ -53,11 +53,12 @@ __device__ __forceinline__ float kan_wprime(const float* bw, const float* sw, co
     return j == 0 ? bw[f] : sw[f * 8 + (j - 1)] * sc[f];
 }
 
-__global__ void pack_x3_kernel(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
-                               unsigned short* __restrict__ wp, int mode, int Cin, int Cout, int NT, int NCH, int T) {
+__device__ __forceinline__ void pack_x3_body(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+                                             unsigned short* __restrict__ wp, int mode, int Cin, int Cout, int NT, int NCH, int T,
+                                             size_t first, size_t stride) {
     const size_t total = (size_t)NCH * T * NT * 64 * 8;
     const int nspl = mode == MODE_KAN ? Cin / 4 : 0;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = first; e < total; e += stride) {
         const int j = e & 7, lane = (e >> 3) & 63;
         size_t t = e >> 9;
         const int nt = t % NT;
@@ -83,6 +84,10 @@ __global__ void pack_x3_kernel(const float* __restrict__ w0, const float* __rest
         wp[base] = (unsigned short)hi;
         wp[base + 512] = (unsigned short)lo;
     }
+}
+__global__ void pack_x3_kernel(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+                               unsigned short* __restrict__ wp, int mode, int Cin, int Cout, int NT, int NCH, int T) {
+    pack_x3_body(w0, w1, w2, wp, mode, Cin, Cout, NT, NCH, T, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 // ---- per-span table of the layer's knot vector (KANlayers.py:526-535), spans i = 0..10: U[i] <= x < U[i+1] ------------------
@@ -384,10 +389,11 @@ int dispatch_fwd(const float* x, const float* knots, const void* wp, const float
 // Pack: wpd[(((chunk*9 + tap)*9 + j)*CT + ct)*2 + {hi,lo}][lane][8], k = output channel 32 chunk + 8 (l>>4) + jj, col = channel
 // ct*16 + (l&15), value W'[o][c][j][8 - tap] (the flipped tap turns the transposed convolution into a plain one on dY).
 // =====================================================================================================================
-__global__ void pack_kan_dgrad_x3_kernel(const float* __restrict__ bw, const float* __restrict__ sw, const float* __restrict__ sc,
-                                         unsigned short* __restrict__ wp, int Cin, int Cout, int CT, int NCH) {
+__device__ __forceinline__ void pack_kan_dgrad_x3_body(const float* __restrict__ bw, const float* __restrict__ sw,
+                                                       const float* __restrict__ sc, unsigned short* __restrict__ wp, int Cin, int Cout,
+                                                       int CT, int NCH, size_t first, size_t stride) {
     const size_t total = (size_t)NCH * 9 * 9 * CT * 64 * 8;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = first; e < total; e += stride) {
         const int jj = e & 7, lane = (e >> 3) & 63;
         size_t t = e >> 9;
         const int ct = t % CT;
@@ -403,6 +409,29 @@ __global__ void pack_kan_dgrad_x3_kernel(const float* __restrict__ bw, const flo
         wp[base] = (unsigned short)hi;
         wp[base + 512] = (unsigned short)lo;
     }
+}
+__global__ void pack_kan_dgrad_x3_kernel(const float* __restrict__ bw, const float* __restrict__ sw, const float* __restrict__ sc,
+                                         unsigned short* __restrict__ wp, int Cin, int Cout, int CT, int NCH) {
+    pack_kan_dgrad_x3_body(bw, sw, sc, wp, Cin, Cout, CT, NCH, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+
+// ---- every pack of a training step in ONE launch: blockIdx.y walks a table of jobs that lives in device memory (built once per
+// model by kmu_conv_pack_job, see ops.PackCache); the jobs' sources are the parameters themselves, so a captured hipGraph re-packs
+// the current weights at every replay.  63 pack launches per step (29 conv + 4 KAN dgrad here, 30 HSMSSD) were each the head of
+// a dependent chain.
+struct ConvPackJob {
+    const float* w0;
+    const float* w1;
+    const float* w2;
+    unsigned short* wp;
+    int kind, mode, Cin, Cout, NT, NCH, T, pad;      // kind 0: pack_x3 (mode, Cin, Cout as the kernel sees them), 1: KAN dgrad (NT = CT)
+};
+static_assert(sizeof(ConvPackJob) == 64, "job records are 64 bytes (kmu_pack_job_bytes)");
+__global__ __launch_bounds__(256) void conv_pack_multi_kernel(const ConvPackJob* __restrict__ jobs) {
+    const ConvPackJob j = jobs[blockIdx.y];
+    const size_t first = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (j.kind == 0) pack_x3_body(j.w0, j.w1, j.w2, j.wp, j.mode, j.Cin, j.Cout, j.NT, j.NCH, j.T, first, stride);
+    else pack_kan_dgrad_x3_body(j.w0, j.w1, j.w2, j.wp, j.Cin, j.Cout, j.NT, j.NCH, first, stride);
 }
 
 // dPhi/dx of the 9 features (SiLU', 8 cubic B-spline derivatives): the same span search and triangle as spline_bf16x8;
@@ -860,6 +889,37 @@ extern "C" int kmu_conv3x3_pack_weights_x3(const float* weight, void* wp, int Ci
 
 extern "C" int kmu_conv3x3_pack_weights_dgrad_x3(const float* weight, void* wp, int Cin, int Cout, kmu_stream_t stream) {
     return kmu_conv2d_pack_weights_x3(weight, wp, Cin, Cout, 3, 1, stream);
+}
+
+// ---- job table for conv_pack_multi_kernel.  `table` is HOST memory of njobs * kmu_pack_job_bytes() bytes that the caller then
+// copies to the device; which = 0 KAN forward pack, 1 KAN input-gradient pack, 2 plain forward pack, 3 plain input-gradient pack
+extern "C" size_t kmu_pack_job_bytes(void) { return sizeof(ConvPackJob); }
+
+extern "C" int kmu_conv_pack_job(void* table, int index, int which, const float* w0, const float* w1, const float* w2, void* wp, int Cin,
+                                 int Cout, int ksize) {
+    KMU_REQUIRE(table && index >= 0 && w0 && wp && which >= 0 && which <= 3, "conv_pack_job: bad arguments");
+    KMU_REQUIRE(Cin > 0 && Cout > 0 && ksize_ok(ksize), "conv_pack_job: bad dims Cin=%d Cout=%d k=%d", Cin, Cout, ksize);
+    ConvPackJob j{};
+    j.w0 = w0, j.w1 = w1, j.w2 = w2, j.wp = (unsigned short*)wp;
+    if (which == 0) {
+        KMU_REQUIRE(w1 && w2 && ksize == 3 && Cin % 4 == 0, "conv_pack_job: KAN pack needs spline weights, a 3x3 kernel and Cin %% 4 == 0");
+        j.kind = 0, j.mode = MODE_KAN, j.Cin = Cin, j.Cout = Cout, j.NT = kmu::cdiv(Cout, 16), j.NCH = n_chunks(MODE_KAN, Cin), j.T = 9;
+    } else if (which == 1) {
+        KMU_REQUIRE(w1 && w2 && ksize == 3, "conv_pack_job: KAN input-gradient pack needs spline weights and a 3x3 kernel");
+        j.kind = 1, j.Cin = Cin, j.Cout = Cout, j.NT = kmu::cdiv(Cin, 16), j.NCH = (Cout + 31) / 32, j.T = 9;
+    } else {
+        const int dgrad = which == 3, kin = dgrad ? Cout : Cin, kout = dgrad ? Cin : Cout;
+        j.kind = 0, j.mode = dgrad ? MODE_PLAIN_DGRAD : MODE_PLAIN, j.Cin = kin, j.Cout = kout, j.NT = kmu::cdiv(kout, 16);
+        j.NCH = n_chunks(MODE_PLAIN, kin), j.T = ksize * ksize;
+    }
+    reinterpret_cast<ConvPackJob*>(table)[index] = j;
+    return 0;
+}
+
+extern "C" int kmu_conv_pack_multi(const void* device_table, int njobs, kmu_stream_t stream) {
+    KMU_REQUIRE(device_table && njobs > 0 && njobs <= 65535, "conv_pack_multi: bad arguments");
+    hipLaunchKernelGGL(conv_pack_multi_kernel, dim3(24, njobs), dim3(256), 0, (hipStream_t)stream, (const ConvPackJob*)device_table);
+    return kmu::launch_status("conv_pack_multi");
 }
 
 extern "C" int kmu_kan_conv2d_fwd_x3(const float* x, const float* knots, const void* wp, const float* residual, float* y, int B,

@@ -690,21 +690,24 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
 template <int C>
 int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
                 const float* w_out, const float* D, const float* state, float* dx, float* p_bcdt, float* p_dw, float* p_hz,
-                float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st, int NG = 1) {
+                float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st, int NG = 1,
+                const void* wpk_ext = nullptr) {
     int txA;
     const int TA = tiles_x3<C>(Hs, &txA);
     float* partA = ws;
     float* dhp = partA + (size_t)B * TA * C * NS;
     float* delta = dhp + (size_t)B * C * NS;
-    unsigned short* wpk = reinterpret_cast<unsigned short*>(delta + (size_t)B * NS);
+    unsigned short* wpk = wpk_ext ? (unsigned short*)wpk_ext : reinterpret_cast<unsigned short*>(delta + (size_t)B * NS);
     const size_t la = lds_passA_x3<C>(), lg = (size_t)7 * C * GN * sizeof(float);
     // Pass B: the exact-fp32 kernel (hsmssd_bwd.inc).
     const bool split_dx = passB_split(C, Hs) == 2;      // fp32 pass B at C = 64: two workgroups per tile add into dx
     int rc = 0;
     if (stages & 1) {
-        hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48, NG), dim3(256), 0, st, w_bcdt, w_dw, wpk);
-        rc = kmu::launch_status("hsmssd_bwd pack");
-        if (rc) return rc;
+        if (!wpk_ext) {
+            hipLaunchKernelGGL(hsm_pack_x3_kernel<C>, dim3(48, NG), dim3(256), 0, st, w_bcdt, w_dw, wpk);
+            rc = kmu::launch_status("hsmssd_bwd pack");
+            if (rc) return rc;
+        }
         KMU_MAX_LDS(hsm_bwd_passA_x3<C>, la);
         hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA, NG);
         rc = kmu::launch_status("hsmssd_bwd passA (bf16x3)");
@@ -745,7 +748,7 @@ extern "C" size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs) {
 static int hsmssd_fwd_stages(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
                              const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
                              size_t ws_bytes, int B, int C, int N, int Hs, int stages, kmu_stream_t stream, bool x3 = false,
-                             int groups = 1) {
+                             int groups = 1, const void* wpk = nullptr) {
     KMU_REQUIRE(x && w_bcdt && w_dw && w_hz && w_out && D && y && h && state && ws, "hsmssd_fwd: null pointer");
     KMU_REQUIRE(groups >= 1 && (groups == 1 || x3) && B % groups == 0, "hsmssd_fwd: %d weight groups need the bf16x3 path and B %% groups == 0",
                 groups);
@@ -755,9 +758,9 @@ static int hsmssd_fwd_stages(const float* x, const float* w_bcdt, const float* w
     KMU_REQUIRE(ws_bytes >= kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs) + (size_t)(groups - 1) * pack_x3_elems(C) * 2, "hsmssd_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (x3) {
-        if (C == 16) return fwd_impl_x3<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups);
-        if (C == 32) return fwd_impl_x3<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups);
-        return fwd_impl_x3<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups);
+        if (C == 16) return fwd_impl_x3<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups, wpk);
+        if (C == 32) return fwd_impl_x3<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups, wpk);
+        return fwd_impl_x3<64>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st, groups, wpk);
     }
     if (C == 16) return fwd_impl<16>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
     if (C == 32) return fwd_impl<32>(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, (float*)ws, B, Hs, stages, st);
@@ -882,7 +885,7 @@ static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, c
                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
-                             int Hs, int stages, kmu_stream_t stream, bool x3 = false, int groups = 1) {
+                             int Hs, int stages, kmu_stream_t stream, bool x3 = false, int groups = 1, const void* wpk = nullptr) {
     KMU_REQUIRE(groups >= 1 && (groups == 1 || x3) && B % groups == 0, "hsmssd_bwd: %d weight groups need the bf16x3 path and B %% groups == 0",
                 groups);
     KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial &&
@@ -899,12 +902,12 @@ static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, c
     if (x3) {
         if (C == 16)
             return bwd_impl_x3<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
         if (C == 32)
             return bwd_impl_x3<32>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
         return bwd_impl_x3<64>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups);
+                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
     }
     if (C == 16)
         return bwd_impl<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
@@ -955,4 +958,52 @@ extern "C" int kmu_hsmssd_bwd_stage(const float* x, const float* dy, const float
     KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_bwd_stage: stage must be 0 (pass A), 1 (gate) or 2 (pass B)");
     return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
                              d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream);
+}
+
+// ---- packs made once per step (ops.PackCache): the composite weights packed by the CALLER, shared by forward and backward --------
+extern "C" size_t kmu_hsmssd_pack_elems(int C, int groups) { return pack_x3_elems(C) * (size_t)(groups > 0 ? groups : 1); }
+
+extern "C" int kmu_hsmssd_pack_x3(const float* w_bcdt, const float* w_dw, void* wpk, int C, int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(w_bcdt && w_dw && wpk, "hsmssd_pack_x3: null pointer");
+    KMU_REQUIRE((C == 16 || C == 32 || C == 64) && groups >= 1, "hsmssd_pack_x3: C=%d (16/32/64), groups=%d", C, groups);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) hipLaunchKernelGGL(hsm_pack_x3_kernel<16>, dim3(48, groups), dim3(256), 0, st, w_bcdt, w_dw, (unsigned short*)wpk);
+    else if (C == 32) hipLaunchKernelGGL(hsm_pack_x3_kernel<32>, dim3(48, groups), dim3(256), 0, st, w_bcdt, w_dw, (unsigned short*)wpk);
+    else hipLaunchKernelGGL(hsm_pack_x3_kernel<64>, dim3(48, groups), dim3(256), 0, st, w_bcdt, w_dw, (unsigned short*)wpk);
+    return kmu::launch_status("hsmssd_pack_x3");
+}
+
+// job table as kmu_conv_pack_job: `table` is host memory, kmu_pack_job_bytes() per record
+extern "C" int kmu_hsm_pack_job(void* table, int index, const float* w_bcdt, const float* w_dw, void* wpk, int C, int groups) {
+    KMU_REQUIRE(table && index >= 0 && w_bcdt && w_dw && wpk, "hsm_pack_job: bad arguments");
+    KMU_REQUIRE((C == 16 || C == 32 || C == 64) && groups >= 1, "hsm_pack_job: C=%d (16/32/64), groups=%d", C, groups);
+    HsmPackJob j{};
+    j.w_bcdt = w_bcdt, j.w_dw = w_dw, j.wpk = (unsigned short*)wpk, j.C = C, j.groups = groups;
+    reinterpret_cast<HsmPackJob*>(table)[index] = j;
+    return 0;
+}
+
+extern "C" int kmu_hsm_pack_multi(const void* device_table, int njobs, kmu_stream_t stream) {
+    KMU_REQUIRE(device_table && njobs > 0 && njobs <= 65535, "hsm_pack_multi: bad arguments");
+    hipLaunchKernelGGL(hsm_pack_multi_kernel, dim3(12, njobs), dim3(256), 0, (hipStream_t)stream, (const HsmPackJob*)device_table);
+    return kmu::launch_status("hsm_pack_multi");
+}
+
+// the *_g stage entry points with the pack handed in (wpk from kmu_hsmssd_pack_x3 / kmu_hsm_pack_multi; NULL = pack here)
+extern "C" int kmu_hsmssd_fwd_stage_x3_pk(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                                          const float* w_out, const float* D, float* y, float* h, float* state, void* ws,
+                                          size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, const void* wpk,
+                                          kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_fwd_stage_x3_pk: stage must be 0 (pass 1), 1 (gate) or 2 (pass 2)");
+    return hsmssd_fwd_stages(x, w_bcdt, w_dw, w_hz, w_out, D, y, h, state, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups, wpk);
+}
+extern "C" int kmu_hsmssd_bwd_stage_x3_pk(const float* x, const float* dy, const float* dh, const float* w_bcdt,
+                                          const float* w_dw, const float* w_hz, const float* w_out, const float* D,
+                                          const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
+                                          float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, void* ws,
+                                          size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, const void* wpk,
+                                          kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "hsmssd_bwd_stage_x3_pk: stage must be 0 (pass A), 1 (gate) or 2 (pass B)");
+    return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
+                             d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups, wpk);
 }

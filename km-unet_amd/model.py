@@ -38,10 +38,14 @@ _SIDE = {}
 _PYR = {}
 
 
+_PYR_STREAMS = int(_os.environ.get("KMU_PYR_STREAMS", "2"))      # 2: one stream per pyramid, 1: both on one, 0: on the main stream
+
+
 def _pyramid_streams(device):
     key = (device.type, device.index)
     if key not in _PYR:
-        _PYR[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        a = torch.cuda.Stream(device=device)
+        _PYR[key] = (a, torch.cuda.Stream(device=device) if _PYR_STREAMS >= 2 else a)
     return _PYR[key]
 
 
@@ -380,7 +384,7 @@ class KM_UNetV3(nn.Module):
         # autograd replays their backward on the same streams, beside the decoder's.
         h2, w2 = e2.shape[2:]
         pyr = [None, None]
-        if x.is_cuda and _BRANCH_STREAMS and h2 % 2 == 0 and w2 % 2 == 0:
+        if x.is_cuda and _BRANCH_STREAMS and _PYR_STREAMS > 0 and h2 % 2 == 0 and w2 % 2 == 0:
             cur = torch.cuda.current_stream()
             ready = cur.record_event()
             for i, (st, att, size) in enumerate(zip(_pyramid_streams(x.device), (self.attention1, self.attention2),

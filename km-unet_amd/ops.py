@@ -235,6 +235,116 @@ def _issue_batched(batch):
                                         ip(*[p.shape[0] for p, _ in ch]), ip(*[max(1, o.numel()) for _, o in ch]), st), "kmu_colsum_multi")
 
 
+# ------------------------------------------------------------------------------------------ weight packs, once per step
+# The split-bf16 kernels (K1, the plain KxK convolutions, K2) read fragment-ordered (hi, lo) packs of their weights.  Packing
+# where the weight is used costs 63 tiny launches per training step (29 conv + 4 KAN input-gradient + 15 + 15 HSMSSD), each the
+# head of a dependent chain.  Inside `pack_scope()` -- train.TrainStep opens one around forward + backward -- a pack made from a
+# Parameter is kept in a persistent buffer and reused by every later consumer of the same step (K2's backward reuses the
+# forward's); from the second step on `prepack()` refills ALL known packs with two launches (one job table per source file:
+# kmu_conv_pack_multi, kmu_hsm_pack_multi) at the head of the step, so a captured hipGraph starts with them and every replay
+# re-packs the current weights.  Outside a scope nothing is cached: a bare forward always packs the weights it is given.
+PACK_ONCE = os.environ.get("KMU_PACK_ONCE", "1") == "1"
+
+
+class PackCache:
+    def __init__(self):
+        self.enabled = False
+        self.epoch = 0
+        self.entries = {}        # key -> [buffer, epoch packed, source tensors (kept alive: the key holds their addresses), job]
+        self.plan = None
+        self.dirty = False
+
+    def clear(self):
+        self.entries.clear()
+        self.plan, self.dirty = None, False
+
+    def build_plan(self, device):
+        import numpy as np
+        lib = _lib.load()
+        rec = lib.kmu_pack_job_bytes()
+        conv = [e for e in self.entries.values() if e[3][0] == "conv"]
+        hsm = [e for e in self.entries.values() if e[3][0] == "hsm"]
+        tabs = []
+        for group in (conv, hsm):
+            if not group:
+                tabs.append(None)
+                continue
+            host = np.zeros(len(group) * rec, dtype=np.uint8)
+            for i, (buf, _, srcs, job) in enumerate(group):
+                if job[0] == "conv":
+                    _, which, Cin, Cout, K = job
+                    ptrs = [_ptr(t) for t in srcs] + [None] * (3 - len(srcs))
+                    _lib.check(lib.kmu_conv_pack_job(host.ctypes.data, i, which, ptrs[0], ptrs[1], ptrs[2], _ptr(buf), Cin, Cout, K),
+                               "kmu_conv_pack_job")
+                else:
+                    _, C, groups = job
+                    _lib.check(lib.kmu_hsm_pack_job(host.ctypes.data, i, _ptr(srcs[0]), _ptr(srcs[1]), _ptr(buf), C, groups), "kmu_hsm_pack_job")
+            tabs.append((torch.from_numpy(host).to(device), len(group)))
+        self.plan, self.dirty = tabs, False
+
+
+_PACKS = PackCache()
+
+
+class pack_scope:
+    """with pack_scope(): one training step's forward + backward -- weights do not change inside."""
+
+    def __enter__(self):
+        self.outer = _PACKS.enabled
+        if not self.outer and PACK_ONCE:
+            _PACKS.enabled = True
+            _PACKS.epoch += 1
+        return self
+
+    def __exit__(self, *exc):
+        _PACKS.enabled = self.outer
+        return False
+
+
+def prepack():
+    """Refill every pack seen so far from the current weights (two launches); call at the head of a pack_scope."""
+    pc = _PACKS
+    if not pc.enabled or not pc.entries:
+        return
+    if pc.dirty or pc.plan is None:
+        if torch.cuda.is_current_stream_capturing():      # the job table needs a host-to-device copy: packs stay lazy this step
+            return
+        pc.build_plan(next(iter(pc.entries.values()))[0].device)
+    lib, st = _lib.load(), _stream()
+    for tab, fn, nm in zip(pc.plan, (lib.kmu_conv_pack_multi, lib.kmu_hsm_pack_multi), ("conv_pack_multi", "hsm_pack_multi")):
+        if tab is not None:
+            _lib.check(_call((nm, (tab[1],)), fn, _ptr(tab[0]), tab[1], st), "kmu_" + nm)
+    for e in pc.entries.values():
+        e[1] = pc.epoch
+
+
+def _pack_ok(origs, convs):
+    """Cacheable: the op was handed Parameters and reads them in place (fp32, contiguous)."""
+    return all(isinstance(o, torch.nn.Parameter) and o.data_ptr() == c.data_ptr() for o, c in zip(origs, convs))
+
+
+def _packed(ok, srcs, nelems, job, pack_fn):
+    """The bf16 pack buffer for `job` over the source tensors: cached per step inside a pack_scope, a fresh pack otherwise."""
+    pc = _PACKS
+    if not (ok and pc.enabled):
+        buf = torch.empty(nelems, device=srcs[0].device, dtype=torch.bfloat16)
+        pack_fn(buf)
+        return buf
+    key = job + tuple(t.data_ptr() for t in srcs)
+    e = pc.entries.get(key)
+    if e is None:
+        if torch.cuda.is_current_stream_capturing():      # a persistent buffer must not come from the graph's private pool
+            buf = torch.empty(nelems, device=srcs[0].device, dtype=torch.bfloat16)
+            pack_fn(buf)
+            return buf
+        e = pc.entries[key] = [torch.empty(nelems, device=srcs[0].device, dtype=torch.bfloat16), -1, tuple(srcs), job]
+        pc.dirty = True
+    if e[1] != pc.epoch:
+        pack_fn(e[0])
+        e[1] = pc.epoch
+    return e[0]
+
+
 # ------------------------------------------------------------------------------------------ K1
 import os as _os
 
@@ -276,7 +386,9 @@ class KanConv2dFn(torch.autograd.Function):
         ctx.defer_wgrad = _leaf(base_w, spline_w, scaler)
         lib = _lib.load()
         x = _f32c(x, "x")
+        origs = (base_w, spline_w, scaler)
         base_w, spline_w, scaler = _f32c(base_w, "base_weight"), _f32c(spline_w, "spline_weight"), _f32c(scaler, "spline_scaler")
+        ctx.pack_ok = _pack_ok(origs, (base_w, spline_w, scaler))
         knots, uniform = _check_grid(grid)
         B, Cin, H, W = x.shape
         Cout = base_w.shape[0]
@@ -294,9 +406,9 @@ class KanConv2dFn(torch.autograd.Function):
         if residual is not None:
             residual = _f32c(residual, "residual")
         if x3:
-            wp3 = torch.empty(lib.kmu_conv3x3_x3_pack_elems(1, Cin, Cout), device=x.device, dtype=torch.bfloat16)
-            _lib.check(lib.kmu_kan_pack_weights_x3(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wp3), Cin, Cout, st),
-                       "kmu_kan_pack_weights_x3")
+            wp3 = _packed(ctx.pack_ok, (base_w, spline_w, scaler), lib.kmu_conv3x3_x3_pack_elems(1, Cin, Cout), ("conv", 0, Cin, Cout, 3),
+                          lambda buf: _lib.check(lib.kmu_kan_pack_weights_x3(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(buf), Cin, Cout,
+                                                                             st), "kmu_kan_pack_weights_x3"))
             _lib.check(_call(("kan_conv2d_fwd_x3", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_fwd_x3, _ptr(x), _ptr(knots), _ptr(wp3),
                              _ptr(residual), _ptr(y), B, Cin, Cout, H, W, 1 if relu else 0, st), "kmu_kan_conv2d_fwd_x3")
         else:
@@ -324,9 +436,9 @@ class KanConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if ctx.x3:       # matrix core: conv3x3(dy, flipped W') per basis + the dPhi epilogue
-                wpd = torch.empty(lib.kmu_kan_dgrad_x3_pack_elems(Cin, Cout), device=x.device, dtype=torch.bfloat16)
-                _lib.check(lib.kmu_kan_pack_weights_dgrad_x3(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(wpd), Cin, Cout, st),
-                           "kmu_kan_pack_weights_dgrad_x3")
+                wpd = _packed(ctx.pack_ok, (base_w, spline_w, scaler), lib.kmu_kan_dgrad_x3_pack_elems(Cin, Cout), ("conv", 1, Cin, Cout, 3),
+                              lambda buf: _lib.check(lib.kmu_kan_pack_weights_dgrad_x3(_ptr(base_w), _ptr(spline_w), _ptr(scaler), _ptr(buf),
+                                                                                       Cin, Cout, st), "kmu_kan_pack_weights_dgrad_x3"))
                 _lib.check(_call(("kan_conv2d_bwd_input_x3", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_input_x3, _ptr(x), _ptr(dy),
                                  _ptr(knots), _ptr(wpd), _ptr(dx), B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_input_x3")
             else:
@@ -369,15 +481,18 @@ class ConvKxKFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.defer_wgrad = _leaf(weight, bias)
         lib = _lib.load()
+        orig = weight
         x, weight = _f32c(x, "x"), _f32c(weight, "weight")
+        ctx.pack_ok = _pack_ok((orig,), (weight,))
         bias = _f32c(bias, "bias") if bias is not None else None
         B, Cin, H, W = x.shape
         Cout, K = weight.shape[0], weight.shape[-1]
         if tuple(weight.shape) != (Cout, Cin, K, K) or K not in (3, 5, 7):
             raise RuntimeError("conv_kxk: weight %s does not match Cin=%d and a 3x3 / 5x5 / 7x7 kernel" % (tuple(weight.shape), Cin))
         st = _stream()
-        wp = torch.empty(lib.kmu_conv2d_x3_pack_elems(Cin, Cout, K), device=x.device, dtype=torch.bfloat16)
-        _lib.check(lib.kmu_conv2d_pack_weights_x3(_ptr(weight), _ptr(wp), Cin, Cout, K, 0, st), "kmu_conv2d_pack_weights_x3")
+        wp = _packed(ctx.pack_ok, (weight,), lib.kmu_conv2d_x3_pack_elems(Cin, Cout, K), ("conv", 2, Cin, Cout, K),
+                     lambda buf: _lib.check(lib.kmu_conv2d_pack_weights_x3(_ptr(weight), _ptr(buf), Cin, Cout, K, 0, st),
+                                            "kmu_conv2d_pack_weights_x3"))
         y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
         _lib.check(_call(("conv%dx%d_fwd_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_fwd_x3, _ptr(x), _ptr(wp), _ptr(bias), _ptr(y),
                          B, Cin, Cout, H, W, K, st), "kmu_conv2d_fwd_x3")
@@ -395,8 +510,9 @@ class ConvKxKFn(torch.autograd.Function):
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:       # dx = conv(dy, flipped / transposed weights) on the same kernel
-            wp = torch.empty(lib.kmu_conv2d_x3_pack_elems(Cout, Cin, K), device=x.device, dtype=torch.bfloat16)
-            _lib.check(lib.kmu_conv2d_pack_weights_x3(_ptr(weight), _ptr(wp), Cin, Cout, K, 1, st), "kmu_conv2d_pack_weights_x3 (dgrad)")
+            wp = _packed(ctx.pack_ok, (weight,), lib.kmu_conv2d_x3_pack_elems(Cout, Cin, K), ("conv", 3, Cin, Cout, K),
+                         lambda buf: _lib.check(lib.kmu_conv2d_pack_weights_x3(_ptr(weight), _ptr(buf), Cin, Cout, K, 1, st),
+                                                "kmu_conv2d_pack_weights_x3 (dgrad)"))
             dx = torch.empty_like(x)
             _lib.check(_call(("conv%dx%d_dgrad_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_fwd_x3, _ptr(dy), _ptr(wp), None, _ptr(dx),
                              B, Cout, Cin, H, W, K, st), "kmu_conv2d_fwd_x3 (dgrad)")
@@ -494,6 +610,12 @@ def layernorm1d(x, weight, bias, eps=1e-5):
     return LayerNorm1dFn.apply(x, weight, bias, eps)
 
 
+def _hsm_pack(ok, w_bcdt, w_dw, C, st):
+    lib = _lib.load()
+    return _packed(ok, (w_bcdt, w_dw), lib.kmu_hsmssd_pack_elems(C, 1), ("hsm", C, 1),
+                   lambda buf: _lib.check(lib.kmu_hsmssd_pack_x3(_ptr(w_bcdt), _ptr(w_dw), _ptr(buf), C, 1, st), "kmu_hsmssd_pack_x3"))
+
+
 class HsmssdFn(torch.autograd.Function):
     """(y[B,C,Hs,Hs], h[B,C,N]) = HSMSSD(x[B,C,L])  (efficient_vim_init.py:33-61)."""
 
@@ -506,7 +628,9 @@ class HsmssdFn(torch.autograd.Function):
         if Hs * Hs != L:
             raise RuntimeError("HSMSSD: L=%d is not a perfect square (reference: int(math.sqrt(L)))" % L)
         N = A.shape[0]
+        origs = (w_bcdt, w_dw)
         w_bcdt, w_dw = _f32c(w_bcdt, "BCdt_proj.weight").reshape(3 * N, C), _f32c(w_dw, "dw.weight").reshape(3 * N, 9)
+        ctx.pack_ok = _pack_ok(origs, (w_bcdt, w_dw))
         w_hz, w_out, D = _f32c(w_hz, "hz_proj.weight").reshape(2 * C, C), _f32c(w_out, "out_proj.weight").reshape(C, C), _f32c(D, "D")
         dev = x.device
         y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
@@ -516,10 +640,12 @@ class HsmssdFn(torch.autograd.Function):
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
         st = _stream()
         x3 = K2_MATH == "bf16x3"
-        fn = lib.kmu_hsmssd_fwd_stage_x3 if x3 else lib.kmu_hsmssd_fwd_stage
+        fn, tail = lib.kmu_hsmssd_fwd_stage, (st,)
+        if x3:      # composite-weight pack: per step when the weights are Parameters inside a pack_scope, else made here
+            fn, tail = lib.kmu_hsmssd_fwd_stage_x3_pk, (1, _ptr(_hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st)), st)
         for stage, nm in enumerate(("hsmssd_fwd_pass1", "hsmssd_fwd_gate", "hsmssd_fwd_pass2")):   # one kernel per call
             _lib.check(_call((nm + ("_x3" if x3 and stage != 1 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
-                             _ptr(w_out), _ptr(D), _ptr(y), _ptr(h), _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, stage, st),
+                             _ptr(w_out), _ptr(D), _ptr(y), _ptr(h), _ptr(state), _ptr(ws), nbytes, B, C, N, Hs, stage, *tail),
                        "kmu_hsmssd_fwd_stage")
         ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
         ctx.set_materialize_grads(False)      # EfficientViMBlock drops h: no zero tensor for its gradient
@@ -548,11 +674,13 @@ class HsmssdFn(torch.autograd.Function):
         nbytes = (lib.kmu_hsmssd_bwd_ws_bytes_x3 if x3 else lib.kmu_hsmssd_bwd_ws_bytes)(B, C, N, Hs)
         ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
         st = _stream()
-        fn = lib.kmu_hsmssd_bwd_stage_x3 if x3 else lib.kmu_hsmssd_bwd_stage
+        fn, tail = lib.kmu_hsmssd_bwd_stage, (st,)
+        if x3:
+            fn, tail = lib.kmu_hsmssd_bwd_stage_x3_pk, (1, _ptr(_hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st)), st)
         for stage, nm in enumerate(("hsmssd_bwd_passA", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
             _lib.check(_call((nm + ("_x3" if x3 and stage == 0 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
                              _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
-                             _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, st), "kmu_hsmssd_bwd_stage")
+                             _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, *tail), "kmu_hsmssd_bwd_stage")
         # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd
         # returns ~1e-7 rounding noise here)
         mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)

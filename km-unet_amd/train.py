@@ -9,6 +9,7 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .dp import DataParallel, live_parameters
 from .loss import HybridLoss
 
@@ -38,9 +39,12 @@ class TrainStep:
 
     def forward_backward(self, data):
         inp, tgt = split_frames(data)
-        out = self.model(inp)
-        loss = self.criterion(out, tgt)
-        self.dp.backward(loss)
+        # the weights do not change between here and the optimizer: every split-bf16 weight pack is made once (ops.PackCache)
+        with ops.pack_scope():
+            ops.prepack()
+            out = self.model(inp)
+            loss = self.criterion(out, tgt)
+            self.dp.backward(loss)
         return loss
 
     def __call__(self, data):

@@ -1012,6 +1012,45 @@ def test_resize_bilinear_vs_torch_cpu(B, C, Hi, Wi, Ho, Wo):
     _report("resize %s" % ((B, C, Hi, Wi, Ho, Wo),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad))
 
 
+def test_pack_once_per_step_matches_per_call_packs():
+    """ops.PackCache: inside a pack_scope the split-bf16 weight packs of K1, a plain 3x3 conv and K2 are made once per step (lazily
+    in the first step, by the two multi-job launches of ops.prepack() afterwards) -- bit-identical results to packing per call, and
+    a weight update between steps must be seen by the next step's packs."""
+    from km_unet_amd import nn as knn
+    ops = _ops()
+    torch.manual_seed(5)
+    kan = knn.KANConv2d(16, 16, 3, 1, 1).to(DEV)
+    conv = torch.nn.Conv2d(16, 32, 3, padding=1).to(DEV)
+    mixer = knn.HSMSSD(32).to(DEV)
+    x = torch.randn(2, 16, 32, 32, device=DEV)
+    params = list(kan.parameters()) + list(conv.parameters()) + list(mixer.parameters())
+
+    def step():
+        xx = x.clone().requires_grad_(True)
+        y = ops.conv_kxk(kan(xx), conv.weight, conv.bias)
+        y = mixer(y.flatten(2))[0]
+        y.square().mean().backward()
+        out = [y.detach().clone(), xx.grad.clone()] + [p.grad.clone() for p in params if p.grad is not None]
+        for p in params:
+            p.grad = None
+        return out
+
+    ops._PACKS.clear()
+    for it in range(3):          # step 0: lazy packs; steps 1, 2: prepack() launches
+        ref = step()
+        with ops.pack_scope():
+            ops.prepack()
+            got = step()
+        assert len(ops._PACKS.entries) >= 4 and (it == 0 or not ops._PACKS.dirty)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), ("pack cache changed a result", it)
+        with torch.no_grad():
+            for p in params:
+                p.mul_(1.0 + 0.05 * (it + 1))
+    assert not ops._PACKS.enabled
+    ops._PACKS.clear()
+
+
 def test_iwp_golden():
     import km_unet_amd
     from oracle.model import fill_parameters
