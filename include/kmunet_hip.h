@@ -245,6 +245,10 @@ int kmu_pwconv_bwd_input(const float* gy, const float* w, const float* x_pre, fl
                          int act_in, kmu_stream_t stream);
 /* dx = W^T * gy + addend  (addend [B,Ci,P]: the gradient that reaches the same tensor along another path, e.g. the blend
  * partner of EfficientViMBlock's FFN stage -- saves autograd's separate fan-in add) */
+/* dx = W^T gy + row_add[b][ci] * row_mul -- the input gradient of a 1x1 conv whose input x ALSO fed a global spatial mean
+ * (DirectionAttention.forward, KM_UNetV3_SH.py:231 and :258): row_add = d mean [B,Ci], row_mul = 1 / (H*W). */
+int kmu_pwconv_bwd_input_rowadd(const float* gy, const float* w, const float* row_add, float row_mul, float* dx, int B, int Ci, int Co,
+                                int P, kmu_stream_t stream);
 int kmu_pwconv_bwd_input_add(const float* gy, const float* w, const float* addend, float* dx, int B, int Ci, int Co, int P,
                              kmu_stream_t stream);
 size_t kmu_pwconv_bwd_weight_ws_bytes(int B, int Ci, int Co, int P);
@@ -360,6 +364,10 @@ int kmu_gate_mlp_bwd(const float* p, const float* w1, const float* w2, const flo
  * arrays src[k] = [rows[k]][cols[k]] -> dst[k] = [cols[k]] in one launch.  srcs/dsts/rows/cols are HOST arrays of
  * length n holding device pointers / sizes.  (No reference counterpart: autograd's SumBackward does this.)
  * ------------------------------------------------------------------------------------ */
+/* Gather copy of `count` contiguous fp32 tensors: dsts[i][0..numel[i]) = srcs[i][...] (host arrays of device pointers; the triples
+ * ride in the kernel arguments, 160 per launch).  Used for the parameter gradients -> flat gradient bucket copy that closes the
+ * backward pass (DataParallel; train_shanghai.py:175-176 has loss.backward() fill .grad in place). */
+int kmu_copy_multi(int count, const float* const* srcs, float* const* dsts, const long long* numel, kmu_stream_t stream);
 int kmu_colsum_multi(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols,
                      kmu_stream_t stream);
 

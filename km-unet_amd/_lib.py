@@ -80,6 +80,7 @@ SIGNATURES = {
     "kmu_gate_mlp_fwd": (_I, [_P] * 7 + [_I] * 6 + [_P]),
     "kmu_gate_mlp_bwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "kmu_colsum_multi": (_I, [_I, _P, _P, _P, _P, _P]),
+    "kmu_copy_multi": (_I, [_I, _P, _P, _P, _P]),
     "kmu_group_norm_splits": (_I, [_I]),
     "kmu_group_norm_fwd": (_I, [_P] * 6 + [_I] * 4 + [_c.c_float, _P]),
     "kmu_group_norm_bwd": (_I, [_P] * 8 + [_I] * 4 + [_P]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "kmu_dwconv3x3_bwd_data": (_I, [_P] * 3 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_bwd_data_add": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_pwconv_bwd_input_add": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "kmu_pwconv_bwd_input_rowadd": (_I, [_P] * 3 + [_c.c_float, _P] + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_partials": (_I, [_I]),
     "kmu_dwconv3x3_bwd_weight": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_conv3x3_x3_pack_elems": (_Z, [_I, _I, _I]),

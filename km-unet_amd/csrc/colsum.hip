@@ -44,7 +44,60 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumArgs a) {
     }
 }
 
+// ---- gather copy: the step's parameter gradients (664 small tensors) into their slots of the flat gradient bucket.  ATen's
+// _foreach_copy_ needs 11 launches / ~150 us for them at the very end of the step (nothing overlaps it); here the (src, dst, n)
+// triples ride in the kernel arguments, 160 per launch, one 256-thread block per 4096-element chunk.
+constexpr int CPY_MAX = 160, CPY_CHUNK = 4096;
+struct CopyArgs {
+    const float* src[CPY_MAX];
+    float* dst[CPY_MAX];
+    int n[CPY_MAX], blk0[CPY_MAX + 1];
+    int count;
+};
+static_assert(sizeof(CopyArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+__global__ __launch_bounds__(256) void copy_multi_kernel(CopyArgs a) {
+    int lo = 0, hi = a.count;                       // blk0[lo] <= blockIdx.x < blk0[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)blockIdx.x >= a.blk0[mid]) lo = mid;
+        else hi = mid;
+    }
+    const float* __restrict__ s = a.src[lo];
+    float* __restrict__ d = a.dst[lo];
+    const int n = a.n[lo], e0 = (blockIdx.x - a.blk0[lo]) * CPY_CHUNK;
+    const int e1 = e0 + CPY_CHUNK < n ? e0 + CPY_CHUNK : n;
+    if ((((size_t)s | (size_t)d) & 15) == 0) {
+        const int v1 = e0 + ((e1 - e0) & ~3);
+        for (int e = e0 + 4 * threadIdx.x; e < v1; e += 1024) *reinterpret_cast<kmu::floatx4*>(d + e) = *reinterpret_cast<const kmu::floatx4*>(s + e);
+        for (int e = v1 + threadIdx.x; e < e1; e += 256) d[e] = s[e];
+    } else {
+        for (int e = e0 + threadIdx.x; e < e1; e += 256) d[e] = s[e];
+    }
+}
+
 }  // namespace
+
+extern "C" int kmu_copy_multi(int count, const float* const* srcs, float* const* dsts, const long long* numel, kmu_stream_t stream) {
+    KMU_REQUIRE(count > 0 && srcs && dsts && numel, "copy_multi: bad arguments");
+    for (int first = 0; first < count; first += CPY_MAX) {
+        CopyArgs a;
+        a.count = count - first < CPY_MAX ? count - first : CPY_MAX;
+        int blocks = 0;
+        for (int k = 0; k < a.count; ++k) {
+            const long long n = numel[first + k];
+            KMU_REQUIRE(srcs[first + k] && dsts[first + k] && n > 0 && n < (1ll << 31), "copy_multi: tensor %d is empty, null or too large", first + k);
+            a.src[k] = srcs[first + k];
+            a.dst[k] = dsts[first + k];
+            a.n[k] = (int)n;
+            a.blk0[k] = blocks;
+            blocks += (int)((n + CPY_CHUNK - 1) / CPY_CHUNK);
+        }
+        a.blk0[a.count] = blocks;
+        hipLaunchKernelGGL(copy_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return kmu::launch_status("copy_multi");
+}
 
 extern "C" int kmu_colsum_multi(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols,
                                 kmu_stream_t stream) {

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
                                                       long w_sk, const float* __restrict__ bias,
                                                       const float* __restrict__ mul_pre, const float* __restrict__ addend,
                                                       float* __restrict__ y, int K, int N, int P, int act_in, int G, long w_sg,
-                                                      const float* __restrict__ bscale, float* __restrict__ stat_part) {
+                                                      const float* __restrict__ bscale, float* __restrict__ stat_part, long bias_sb,
+                                                      float bias_mul) {
+    // bias_sb: per-sample stride of `bias` (0 = one vector for the whole batch), bias_mul its factor: the input gradient of a conv
+    // whose input ALSO feeds a spatial mean adds d_mean[b][n] / HW to every pixel here instead of in an ATen broadcast add
     // G > 1: grouped convolution (block-diagonal weights): x has G*K channels, y has N = G*Ng channels, tile n0 belongs to group
     // n0 / Ng and contracts that group's K input channels with w + g*w_sg indexed by the LOCAL output channel
     extern __shared__ float wl[];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + 16 * nt + m;
-        const float bv = bias ? bias[n] : 0.f;
+        const float bv = bias ? bias[(size_t)b * bias_sb + n] * bias_mul : 0.f;
         sta[nt] = stq[nt] = 0.f;
         const float sc = bscale ? bscale[b] : 1.f;       // per-sample factor (DropPath's mask / keep_prob of a residual branch)
         const size_t off = ((size_t)b * N + n) * P + p0 + 4 * q;
@@ -420,17 +423,17 @@ inline WgradPlan wgrad_plan(int B, int Ci, int Co, int P) {
 template <int NT>
 int launch_gemm(const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, const float* addend,
                 float* y, int B, int K, int N, int P, int act_in, hipStream_t st, int G, long w_sg, const float* bscale,
-                float* stat_part) {
+                float* stat_part, long bias_sb, float bias_mul) {
     const size_t lds = (size_t)(K < KT_MAX ? K : KT_MAX) * lds_stride(NT) * sizeof(float);
     KMU_MAX_LDS((pw_gemm_kernel<NT>), lds);
     hipLaunchKernelGGL((pw_gemm_kernel<NT>), dim3(B * ((P + 255) / 256), N / (16 * NT)), dim3(256), lds, st, x, w, w_sn, w_sk, bias,
-                       mul_pre, addend, y, K, N, P, act_in, G, w_sg, bscale, stat_part);
+                       mul_pre, addend, y, K, N, P, act_in, G, w_sg, bscale, stat_part, bias_sb, bias_mul);
     return 0;
 }
 
 int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk, const float* bias, const float* mul_pre, float* y,
          int B, int K, int N, int P, int act_in, hipStream_t st, const float* addend = nullptr, int G = 1, long w_sg = 0,
-         const float* bscale = nullptr, float* stat_part = nullptr) {
+         const float* bscale = nullptr, float* stat_part = nullptr, long bias_sb = 0, float bias_mul = 1.f) {
     // K = contraction channels PER GROUP, N = output channels in total (G groups of N / G)
     KMU_REQUIRE(B > 0 && K > 0 && N > 0 && K % 16 == 0 && N % 16 == 0, "%s: channels (%d -> %d) must be positive multiples of 16",
                 what, K, N);
@@ -443,10 +446,10 @@ int gemm(const char* what, const float* x, const float* w, long w_sn, long w_sk,
     const long blocks_x = (long)B * ((P + 255) / 256);
     while (nt > 1 && blocks_x * (N / (16 * nt)) < 192) nt = (nt == 4) ? 2 : 1;
     switch (nt) {
-        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
-        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
-        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
-        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part); break;
+        case 4: launch_gemm<4>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part, bias_sb, bias_mul); break;
+        case 3: launch_gemm<3>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part, bias_sb, bias_mul); break;
+        case 2: launch_gemm<2>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part, bias_sb, bias_mul); break;
+        default: launch_gemm<1>(x, w, w_sn, w_sk, bias, mul_pre, addend, y, B, K, N, P, act_in, st, G, w_sg, bscale, stat_part, bias_sb, bias_mul); break;
     }
     return kmu::launch_status(what);
 }
@@ -481,6 +484,15 @@ extern "C" int kmu_pwconv_bwd_input(const float* gy, const float* w, const float
     KMU_REQUIRE(!act_in || x_pre, "pwconv_bwd_input: act_in needs the pre-activation input");
     // dx[ci] = sum_co W[co][ci] gy[co]: the same contraction with K = Co, N = Ci and w(n = ci, k = co) = W[k*Ci + n]
     return gemm("pwconv_bwd_input", gy, w, 1, Ci, nullptr, act_in ? x_pre : nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream);
+}
+
+// dx = W^T gy + row_add[b][ci] * row_mul: the conv's input also fed a spatial mean whose gradient is d_mean = row_add, row_mul = 1 / HW
+// (DirectionAttention.forward, KM_UNetV3_SH.py:231 + :258: AdaptiveAvgPool2d(1)(x) and qkv(x) read the same x)
+extern "C" int kmu_pwconv_bwd_input_rowadd(const float* gy, const float* w, const float* row_add, float row_mul, float* dx, int B, int Ci,
+                                           int Co, int P, kmu_stream_t stream) {
+    KMU_REQUIRE(gy && w && row_add && dx, "pwconv_bwd_input_rowadd: null pointer");
+    return gemm("pwconv_bwd_input_rowadd", gy, w, 1, Ci, row_add, nullptr, dx, B, Co, Ci, P, 0, (hipStream_t)stream, nullptr, 1, 0, nullptr,
+                nullptr, Ci, row_mul);
 }
 
 extern "C" int kmu_pwconv_bwd_input_add(const float* gy, const float* w, const float* addend, float* dx, int B, int Ci, int Co, int P,

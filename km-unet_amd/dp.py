@@ -64,7 +64,11 @@ class FlatGradBucket:
             else:
                 v.copy_(g)
         if fast_v:
-            torch._foreach_copy_(fast_v, fast_g)
+            if fast_v[0].is_cuda and all(g.is_contiguous() and v.is_contiguous() and g.dtype == torch.float32 for v, g in zip(fast_v, fast_g)):
+                from . import ops
+                ops.copy_multi(fast_v, fast_g)        # 5 launches of a pointer-table copy kernel instead of ATen's 11
+            else:
+                torch._foreach_copy_(fast_v, fast_g)
 
     def numel(self):
         return self.flat.numel()

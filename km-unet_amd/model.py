@@ -38,6 +38,7 @@ _SIDE = {}
 _PYR = {}
 
 
+_MEAN_QKV = _os.environ.get("KMU_MEAN_QKV", "1") == "1"      # DirectionAttention: pool + qkv projection as one autograd node
 _PYR_STREAMS = int(_os.environ.get("KMU_PYR_STREAMS", "2"))      # 2: one stream per pyramid, 1: both on one, 0: on the main stream
 
 
@@ -145,8 +146,12 @@ class DirectionAttention(nn.Module):
 
     def forward(self, x):
         b, c = x.shape[:2]
-        gate = gate_mlp(_spatial_mean(x), self.fc[0], self.fc[2], "gelu")
-        qkv = conv1x1(x, self.qkv)
+        if x.is_cuda and not _TORCH_GLUE and _MEAN_QKV and ops.pwconv_supported(c, 3 * c, x.shape[2] * x.shape[3]):
+            pooled, qkv = ops.mean_pwconv(x, self.qkv.weight, self.qkv.bias)      # one node: no fan-in add in the backward
+            gate = gate_mlp(pooled, self.fc[0], self.fc[2], "gelu")
+        else:
+            gate = gate_mlp(_spatial_mean(x), self.fc[0], self.fc[2], "gelu")
+            qkv = conv1x1(x, self.qkv)
         if (qkv.shape[2] * qkv.shape[3]) % 4 == 0 and "qkv_gate" not in _TORCH_GLUE:
             attn = ops.qkv_gate(qkv)                       # sigmoid(q*k)*v, one HIP kernel
         else:

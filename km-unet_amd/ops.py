@@ -173,6 +173,26 @@ def colsum(*partials, outs=None):
     return [None if p is None else next(it) for p in partials]
 
 
+def copy_multi(dsts, srcs):
+    """dsts[i].copy_(srcs[i]) for contiguous fp32 CUDA tensors of equal numel, 160 per launch (csrc/colsum.hip: kmu_copy_multi)."""
+    import ctypes
+    n = len(dsts)
+    if n == 0:
+        return
+    for d, s_ in zip(dsts, srcs):
+        if not (d.is_cuda and s_.is_cuda and d.dtype == s_.dtype == torch.float32 and d.is_contiguous() and s_.is_contiguous()
+                and d.numel() == s_.numel()):
+            raise RuntimeError("copy_multi: contiguous fp32 CUDA tensors of equal size only")
+    keep = [(d, s_) for d, s_ in zip(dsts, srcs) if d.numel() > 0 and d.data_ptr() != s_.data_ptr()]
+    if not keep:
+        return
+    n = len(keep)
+    sp = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in keep])
+    dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in keep])
+    ne = (ctypes.c_longlong * n)(*[d.numel() for d, _ in keep])
+    _lib.check(_call(("copy_multi", (n,)), _lib.load().kmu_copy_multi, n, sp, dp, ne, _stream()), "kmu_copy_multi")
+
+
 def _pw_wgrad_call(lib, x, gy, dw, db, B, ci, co, P, act_in):
     """kmu_pwconv_bwd_weight, or -- inside the final flush -- only its slab pass, the slab reduction being batched"""
     nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)
@@ -1791,6 +1811,63 @@ class PwConvFn(torch.autograd.Function):
 
 def pwconv(x, weight, bias=None, act_in=False):
     return PwConvFn.apply(x, weight, bias, act_in)
+
+
+class MeanPwConvFn(torch.autograd.Function):
+    """(mean_hw(x) [B,C], conv1x1(x, weight) + bias) as ONE autograd node: DirectionAttention.forward (KM_UNetV3_SH.py:231, :258)
+    pools x for its channel gate and projects the same x to q, k, v.  As two nodes the backward ran a scale launch on d mean, the
+    1x1 input gradient, and an ATen broadcast add of the two at the fan-in; here d mean / HW rides in the input-gradient kernel's
+    epilogue as a per-(sample, channel) constant."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.defer_wgrad = _leaf(weight, bias)
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        co, ci = weight.shape[:2]
+        w = _f32c(weight, "weight").view(co, ci)
+        B, _, H, W = x.shape
+        st = _stream()
+        pooled = torch.empty(B, ci, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("mean_rows", (B, ci, H * W)), lib.kmu_mean_rows, _ptr(x), None, None, _ptr(pooled), B, ci, H * W, 1, st), "kmu_mean_rows")
+        y = torch.empty(B, co, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("pwconv_fwd", (B, ci, co, H * W)), lib.kmu_pwconv_fwd, _ptr(x), _ptr(w),
+                         _ptr(None if bias is None else _f32c(bias, "bias")), _ptr(y), B, ci, co, H * W, 0, st), "kmu_pwconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (bias is not None, tuple(weight.shape))
+        ctx.set_materialize_grads(False)
+        return pooled, y
+
+    @staticmethod
+    def backward(ctx, gp, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        has_bias, wshape = ctx.cfg
+        B, ci, H, W = x.shape
+        co, P = w.shape[0], H * W
+        if g is None:         # only the pooled output was used
+            dx = None
+            if gp is not None and ctx.needs_input_grad[0]:
+                dx = (_f32c(gp, "grad") * (1.0 / P)).view(B, ci, 1, 1).expand(B, ci, H, W)
+            return dx, None, None
+        g = _f32c(g, "grad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if gp is None:
+                _lib.check(_call(("pwconv_bwd_input", (B, ci, co, P)), lib.kmu_pwconv_bwd_input, _ptr(g), _ptr(w), None, _ptr(dx), B, ci, co,
+                                 P, 0, _stream()), "kmu_pwconv_bwd_input")
+            else:
+                _lib.check(_call(("pwconv_bwd_input", (B, ci, co, P)), lib.kmu_pwconv_bwd_input_rowadd, _ptr(g), _ptr(w),
+                                 _ptr(_f32c(gp, "grad")), 1.0 / P, _ptr(dx), B, ci, co, P, _stream()), "kmu_pwconv_bwd_input_rowadd")
+        dw = torch.empty(co, ci, device=x.device, dtype=torch.float32)
+        db = torch.empty(co, device=x.device, dtype=torch.float32) if has_bias else None
+        _wgrad(lambda: _pw_wgrad_call(lib, x, g, dw, db, B, ci, co, P, 0), ctx.defer_wgrad)
+        return dx, dw.view(wshape), db
+
+
+def mean_pwconv(x, weight, bias=None):
+    return MeanPwConvFn.apply(x, weight, bias)
 
 
 # ------------------------------------------------------------------------------------------ wavelet pooling front end

@@ -795,6 +795,34 @@ def test_spatial_mean_vs_torch_cpu(B, C, H, W):
     _report("spatial_mean %s" % ((B, C, H, W),), y=rel_err(m, x.mean(dim=(2, 3))), dx=rel_err(xd.grad, x.grad))
 
 
+@pytest.mark.parametrize("B,C,H,W,use", [(2, 16, 32, 32, "both"), (8, 32, 64, 64, "both"), (3, 64, 8, 16, "both"), (2, 16, 16, 16, "conv"),
+                                         (2, 16, 16, 16, "mean")])
+def test_mean_pwconv_vs_torch_cpu(B, C, H, W, use):
+    """DirectionAttention's pooled gate input and qkv projection of the same x as one node (KM_UNetV3_SH.py:231, :258): both
+    outputs and the three gradients against fp64 torch, with either output unused as well."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(B + C + H)
+    x = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
+    w = (0.3 * torch.randn(3 * C, C, 1, 1, generator=gen, dtype=torch.float64)).requires_grad_(True)
+    b = torch.randn(3 * C, generator=gen, dtype=torch.float64).requires_grad_(True)
+    gp = torch.randn(B, C, generator=gen, dtype=torch.float64)
+    gy = torch.randn(B, 3 * C, H, W, generator=gen, dtype=torch.float64)
+    pooled, y = x.mean(dim=(2, 3)), torch.nn.functional.conv2d(x, w, b)
+    ((pooled * gp).sum() * (use != "conv") + (y * gy).sum() * (use != "mean")).backward()
+    xd, wd, bd = (t.detach().float().to(DEV).requires_grad_(True) for t in (x, w, b))
+    pd, yd = ops.mean_pwconv(xd, wd, bd)
+    loss = 0
+    if use != "conv":
+        loss = loss + (pd * gp.float().to(DEV)).sum()
+    if use != "mean":
+        loss = loss + (yd * gy.float().to(DEV)).sum()
+    loss.backward()
+    errs = dict(pooled=rel_err(pd, pooled), y=rel_err(yd, y), dx=rel_err(xd.grad, x.grad))
+    if use != "mean":
+        errs.update(dw=rel_err(wd.grad, w.grad), db=rel_err(bd.grad, b.grad))
+    _report("mean_pwconv %s %s" % ((B, C, H, W), use), **errs)
+
+
 @pytest.mark.parametrize("B,C,Co,H,W,axis", [(2, 16, 16, 16, 16, 0), (2, 16, 16, 16, 16, 1), (1, 32, 32, 8, 16, 0), (3, 64, 64, 8, 8, 1)])
 def test_conv3tap_vs_torch_cpu(B, C, Co, H, W, axis):
     """(3,1) / (1,3) convolutions as tap stacking (csrc/shift3.hip) + pointwise conv, against F.conv2d in fp64."""
@@ -1010,6 +1038,26 @@ def test_resize_bilinear_vs_torch_cpu(B, C, Hi, Wi, Ho, Wo):
     y = ops.resize_bilinear(xd, (Ho, Wo))
     y.backward(gy.float().to(DEV))
     _report("resize %s" % ((B, C, Hi, Wi, Ho, Wo),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad))
+
+
+def test_copy_multi_matches_foreach_copy():
+    """kmu_copy_multi (gradients -> flat bucket): 700 tensors of ragged sizes at unaligned offsets of one flat buffer, bit-exact."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    sizes = [int(v) for v in torch.randint(1, 3000, (697,), generator=g)] + [1, 147456, 4097]
+    flat = torch.zeros(sum(sizes) + 3, device=DEV)
+    ref = torch.zeros_like(flat)
+    srcs, dsts, refs, off = [], [], [], 3
+    for n in sizes:
+        srcs.append(torch.randn(n, device=DEV))
+        dsts.append(flat[off:off + n])
+        refs.append(ref[off:off + n])
+        off += n
+    ops.copy_multi(dsts, srcs)
+    torch._foreach_copy_(refs, srcs)
+    assert torch.equal(flat, ref)
+    with pytest.raises(RuntimeError):
+        ops.copy_multi([flat[:4]], [torch.zeros(5, device=DEV)])
 
 
 def test_pack_once_per_step_matches_per_call_packs():
