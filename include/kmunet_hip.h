@@ -364,6 +364,10 @@ int kmu_gate_mlp_bwd(const float* p, const float* w1, const float* w2, const flo
  * arrays src[k] = [rows[k]][cols[k]] -> dst[k] = [cols[k]] in one launch.  srcs/dsts/rows/cols are HOST arrays of
  * length n holding device pointers / sizes.  (No reference counterpart: autograd's SumBackward does this.)
  * ------------------------------------------------------------------------------------ */
+/* out = ((a + b) + c) + d over numel floats (c, d may be NULL): the gradient fan-in of a tensor with up to four consumers in one
+ * launch -- EnhancedViMBlock's x feeds the three direction branches and the residual (KM_UNetV3_SH.py:141-146); e1 / e2 feed the
+ * next encoder stage and both MultiScaleFusion pyramids (:487-509).  Autograd itself accumulates pairwise, one launch per extra use. */
+int kmu_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long long numel, kmu_stream_t stream);
 /* Gather copy of `count` contiguous fp32 tensors: dsts[i][0..numel[i]) = srcs[i][...] (host arrays of device pointers; the triples
  * ride in the kernel arguments, 160 per launch).  Used for the parameter gradients -> flat gradient bucket copy that closes the
  * backward pass (DataParallel; train_shanghai.py:175-176 has loss.backward() fill .grad in place). */

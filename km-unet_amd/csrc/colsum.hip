@@ -76,7 +76,37 @@ __global__ __launch_bounds__(256) void copy_multi_kernel(CopyArgs a) {
     }
 }
 
+// out = ((a + b) + c) + d, elementwise, c / d optional: the fan-in of a tensor with up to four consumers in one launch (autograd
+// accumulates pairwise: three adds for EnhancedViMBlock's x, which feeds the three direction branches and the residual)
+__global__ __launch_bounds__(256) void add_n_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                    const float* __restrict__ d, float* __restrict__ out, size_t n4, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        kmu::floatx4 v = reinterpret_cast<const kmu::floatx4*>(a)[i] + reinterpret_cast<const kmu::floatx4*>(b)[i];
+        if (c) v += reinterpret_cast<const kmu::floatx4*>(c)[i];
+        if (d) v += reinterpret_cast<const kmu::floatx4*>(d)[i];
+        reinterpret_cast<kmu::floatx4*>(out)[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+            float v = a[i] + b[i];
+            if (c) v += c[i];
+            if (d) v += d[i];
+            out[i] = v;
+        }
+}
+
 }  // namespace
+
+extern "C" int kmu_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long long numel, kmu_stream_t stream) {
+    KMU_REQUIRE(a && b && out && numel > 0 && (c || !d), "add_n: needs a, b, out (c before d)");
+    const bool vec = ((((size_t)a | (size_t)b | (size_t)c | (size_t)d | (size_t)out) & 15) == 0);
+    const size_t n4 = vec ? (size_t)numel / 4 : 0;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(add_n_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, d, out, n4, (size_t)numel);
+    return kmu::launch_status("add_n");
+}
 
 extern "C" int kmu_copy_multi(int count, const float* const* srcs, float* const* dsts, const long long* numel, kmu_stream_t stream) {
     KMU_REQUIRE(count > 0 && srcs && dsts && numel, "copy_multi: bad arguments");

@@ -38,6 +38,7 @@ _SIDE = {}
 _PYR = {}
 
 
+_FANOUT = _os.environ.get("KMU_FANOUT", "1") == "1"          # multi-consumer tensors: one gradient fan-in launch (ops.fanout)
 _MEAN_QKV = _os.environ.get("KMU_MEAN_QKV", "1") == "1"      # DirectionAttention: pool + qkv projection as one autograd node
 _PYR_STREAMS = int(_os.environ.get("KMU_PYR_STREAMS", "2"))      # 2: one stream per pyramid, 1: both on one, 0: on the main stream
 
@@ -223,21 +224,23 @@ class EnhancedViMBlock(nn.Module):
         self.norm = TripleNorm(dim)
         self.drop_path = DropPath(drop_path) if drop_path > 0 else nn.Identity()
 
-    def _branches(self, x):
+    def _branches(self, x, xw=None, xc=None):
         """The three direction branches are independent: fork them onto side HIP streams (parallel branches of the
         captured hipGraph; autograd replays each branch's backward on the stream it ran on).  Their kernels at the
-        64x64 / 32x32 levels are far too small to fill 256 CUs one at a time."""
+        64x64 / 32x32 levels are far too small to fill 256 CUs one at a time.  xw / xc: aliases of x for the width / channel
+        branch (ops.fanout: one gradient fan-in launch instead of pairwise adds)."""
+        xw, xc = (x if xw is None else xw), (x if xc is None else xc)
         if not (x.is_cuda and _BRANCH_STREAMS):
-            return [self.height_block(x), self.width_block(x), self.channel_block(x)]
+            return [self.height_block(x), self.width_block(xw), self.channel_block(xc)]
         cur = torch.cuda.current_stream()
         side = _side_streams(x.device)
         ready = cur.record_event()
         feats = [None, None, None]
         feats[0] = self.height_block(x)
-        for i, (st, blk) in enumerate(zip(side, (self.width_block, self.channel_block)), start=1):
+        for i, (st, blk, xi) in enumerate(zip(side, (self.width_block, self.channel_block), (xw, xc)), start=1):
             st.wait_event(ready)
             with torch.cuda.stream(st):
-                feats[i] = blk(x)
+                feats[i] = blk(xi)
         for st, f in zip(side, feats[1:]):
             cur.wait_stream(st)
             f.record_stream(cur)          # produced on a side stream, consumed (and later freed) on the main one
@@ -254,7 +257,11 @@ class EnhancedViMBlock(nn.Module):
             x = grouped.GatedMix3StackedFn.apply(x, F3, fg[1].weight, fg[1].bias, fg[3].weight, fg[3].bias,
                                                  dp.scale(x) if dp is not None else None)
             return self._ffn(x, dp)
-        feats = self._branches(x)
+        if x.is_cuda and _FANOUT and not _TORCH_GLUE:
+            x, xh, xw, xc = ops.fanout(x, 4)      # residual + three branches: their four gradients meet in one launch
+            feats = self._branches(xh, xw, xc)
+        else:
+            feats = self._branches(x)
         if x.is_cuda and "mix3" not in _TORCH_GLUE and "gate_mlp" not in _TORCH_GLUE and (x.shape[2] * x.shape[3]) % 4 == 0:
             # pool -> gate MLP -> softmax -> weighted branch sum + DropPath + residual as one autograd node
             x = ops.gated_mix3(x, feats[0], feats[1], feats[2], self.fusion_gate[1], self.fusion_gate[3],
@@ -382,7 +389,11 @@ class KM_UNetV3(nn.Module):
         self._mask_pool.reset()
         x = conv3x3(x.float(), self.conv_f)
         e1 = self.lca1(self.enc1(x))
+        fan = x.is_cuda and _FANOUT and not _TORCH_GLUE
+        # e1 / e2 feed the next encoder stage and both pyramids: aliases whose three gradients meet in one launch (ops.fanout)
+        e1, *e1p = ops.fanout(e1, 3) if fan else (e1, e1, e1)
         e2 = self.lca2(self.enc2(e1))
+        e2, *e2p = ops.fanout(e2, 3) if fan else (e2, e2, e2)
         # The two MultiScaleFusion pyramids read only e1 and e2 (and the SIZE of the decoder feature they are concatenated to:
         # 1x and 2x e2's, the wavelet pooling halves and each decoder stage doubles): ~50 launches forward and ~100 backward that
         # need not sit between the encoder and the decoder on the critical path.  Fork them onto two streams of their own here;
@@ -396,11 +407,11 @@ class KM_UNetV3(nn.Module):
                                                     ((h2, w2), (2 * h2, 2 * w2)))):
                 st.wait_event(ready)
                 with torch.cuda.stream(st):
-                    pyr[i] = (st, self._pyramid(att, e1, e2, size))
+                    pyr[i] = (st, self._pyramid(att, e1p[i], e2p[i], size))
         e3 = self.lca3(self.enc3(e2))
         d1 = self.dec1(self.bridge_attention(e3) if self.variant == "SH" else e3)
-        d1 = torch.cat([d1, self._joined(pyr[0], self.attention1, e1, e2, d1)], dim=1)
+        d1 = torch.cat([d1, self._joined(pyr[0], self.attention1, e1p[0], e2p[0], d1)], dim=1)
         d2 = self.dec2[2](conv3x3(self.dec2[0](d1), self.dec2[1]))
-        d2 = torch.cat([d2, self._joined(pyr[1], self.attention2, e1, e2, d2)], dim=1)
+        d2 = torch.cat([d2, self._joined(pyr[1], self.attention2, e1p[1], e2p[1], d2)], dim=1)
         d3 = conv3x3(self.dec3[2](conv3x3(self.dec3[0](d2), self.dec3[1])), self.dec3[3])
         return self.activation(group_norm(d3, self.output_norm))

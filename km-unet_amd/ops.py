@@ -193,6 +193,42 @@ def copy_multi(dsts, srcs):
     _lib.check(_call(("copy_multi", (n,)), _lib.load().kmu_copy_multi, n, sp, dp, ne, _stream()), "kmu_copy_multi")
 
 
+class FanoutFn(torch.autograd.Function):
+    """n aliases of x for n consumers; the backward sums their gradients in ONE launch (csrc/colsum.hip: kmu_add_n) where autograd's
+    own accumulation runs n - 1 pairwise adds.  Used where a tensor feeds parallel branches (KM_UNetV3_SH.py:141-146, :487-509)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if not gs[0].is_cuda or len(gs) > 4 or any(g.dtype != torch.float32 for g in gs):
+            out = gs[0] + gs[1]
+            for g in gs[2:]:
+                out = out + g
+            return out, None
+        gs = [_f32c(g, "grad") for g in gs]
+        out = torch.empty_like(gs[0])
+        p = [_ptr(g) for g in gs] + [None] * (4 - len(gs))
+        _lib.check(_call(("add_n", (len(gs), out.numel())), _lib.load().kmu_add_n, p[0], p[1], p[2], p[3], _ptr(out), out.numel(), _stream()),
+                   "kmu_add_n")
+        return out, None
+
+
+def fanout(x, n):
+    """n aliases of x whose gradients are summed by one kernel; plain aliases when no gradient is wanted."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return FanoutFn.apply(x, n)
+
+
 def _pw_wgrad_call(lib, x, gy, dw, db, B, ci, co, P, act_in):
     """kmu_pwconv_bwd_weight, or -- inside the final flush -- only its slab pass, the slab reduction being batched"""
     nbytes = lib.kmu_pwconv_bwd_weight_ws_bytes(B, ci, co, P)

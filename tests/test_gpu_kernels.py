@@ -1040,6 +1040,25 @@ def test_resize_bilinear_vs_torch_cpu(B, C, Hi, Wi, Ho, Wo):
     _report("resize %s" % ((B, C, Hi, Wi, Ho, Wo),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad))
 
 
+@pytest.mark.parametrize("n,shape", [(4, (2, 16, 32, 32)), (3, (8, 32, 64, 64)), (2, (3, 5, 7, 9)), (4, (1, 1, 1, 3))])
+def test_fanout_sums_gradients_like_autograd(n, shape):
+    """ops.fanout: n aliases of x, gradients summed by ONE kernel; against autograd's own pairwise accumulation (same values up to the
+    order of three float additions), with one consumer unused as well."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(*shape, generator=gen).to(DEV)
+    ws = [torch.randn(*shape, generator=gen).to(DEV) for _ in range(n)]
+    for skip in (None, 1):
+        xr = x.clone().requires_grad_(True)
+        sum((xr * w).sin().sum() for i, w in enumerate(ws) if i != skip).backward()
+        xf = x.clone().requires_grad_(True)
+        al = ops.fanout(xf, n)
+        assert all(a.data_ptr() == xf.data_ptr() for a in al)
+        sum((a * w).sin().sum() for i, (a, w) in enumerate(zip(al, ws)) if i != skip).backward()
+        _report("fanout %d %s skip=%s" % (n, shape, skip), dx=rel_err(xf.grad, xr.grad))
+    assert ops.fanout(x, 3)[0] is x          # no gradient wanted: plain aliases
+
+
 def test_copy_multi_matches_foreach_copy():
     """kmu_copy_multi (gradients -> flat bucket): 700 tensors of ragged sizes at unaligned offsets of one flat buffer, bit-exact."""
     ops = _ops()
