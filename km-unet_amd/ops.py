@@ -83,7 +83,12 @@ def _ptr(t):
 # Off by default: a bare `.backward()` followed by a read of `.grad` must see finished gradients.
 WGRAD_OVERLAP = False
 WGRAD_BATCH = int(os.environ.get("KMU_WGRAD_BATCH", "4096"))
-WGRAD_STREAMS = int(os.environ.get("KMU_WGRAD_STREAMS", "3"))
+WGRAD_STREAMS = int(os.environ.get("KMU_WGRAD_STREAMS", "4"))      # 3 vs 4 vs 5: within the box-to-box noise (+-0.07 ms)
+# dense-conv weight gradients started where autograd reaches them instead of in the tail: measured neutral (10.17 / 10.22 vs
+# 10.18 / 10.09 ms/step, interleaved on one box) -- the backward chain already keeps the device busy; off by default
+WGRAD_EARLY = os.environ.get("KMU_WGRAD_EARLY", "0") == "1"
+_WG_EARLY = {}
+_WG_EARLY_KEEP = []
 WGRAD_GROUP = os.environ.get("KMU_WGRAD_GROUP", "1") == "1"     # identical pointwise-conv weight gradients share a launch
 _WG_SIDE = {}
 _WG_JOBS = []
@@ -103,9 +108,24 @@ def _leaf(*ts):
     return all(t is None or t.grad_fn is None or type(t.grad_fn).__name__ == "StackParamsFnBackward" for t in ts)
 
 
-def _wgrad(job, defer=True):
+def _wgrad(job, defer=True, heavy=False):
     if not (WGRAD_OVERLAP and defer):
         job()
+        return
+    if heavy and WGRAD_EARLY:
+        # the dense KxK / KAN weight gradients (16 jobs of 30-110 us, ~1 ms per step) are long enough to pay for a cross-stream
+        # edge each: they start at once on a stream of their own, beside the activation-gradient chain, instead of in the tail.
+        # The closure (holding x and dy) is kept until the final join: the producers' allocator must not recycle their blocks
+        # while the side stream still reads them.
+        cur = torch.cuda.current_stream()
+        early = _WG_EARLY.get(cur.device.index)
+        if early is None:
+            early = _WG_EARLY[cur.device.index] = torch.cuda.Stream(device=cur.device)
+        early.wait_event(cur.record_event())
+        with torch.cuda.stream(early):
+            job()
+        _WG_BUSY.add(early)
+        _WG_EARLY_KEEP.append(job)
         return
     _WG_JOBS.append((torch.cuda.current_stream(), job))
     if len(_WG_JOBS) >= WGRAD_BATCH:
@@ -145,6 +165,7 @@ def flush_wgrad_jobs(final=True):
         for side in _WG_BUSY:
             cur.wait_stream(side)
         _WG_BUSY.clear()
+        _WG_EARLY_KEEP.clear()
         if batch:
             _issue_batched(batch)       # on the joining stream, behind every job's first stage
 
@@ -520,7 +541,7 @@ class KanConv2dFn(torch.autograd.Function):
                     _lib.check(_call(("kan_conv2d_bwd_weights", (B, Cin, Cout, H, W)), lib.kmu_kan_conv2d_bwd_weights, _ptr(x), _ptr(dy),
                                      _ptr(knots), _ptr(spline_w), _ptr(scaler), _ptr(d_bw), _ptr(d_sw), _ptr(d_sc), _ptr(ws), nbytes,
                                      B, Cin, Cout, H, W, st), "kmu_kan_conv2d_bwd_weights")
-            _wgrad(job, ctx.defer_wgrad)
+            _wgrad(job, ctx.defer_wgrad, heavy=True)
         return dx, None, d_bw, d_sw, d_sc, (dy if ctx.has_res else None), None
 
 
@@ -586,7 +607,7 @@ class ConvKxKFn(torch.autograd.Function):
             if db is not None:
                 torch.sum(dy, dim=(0, 2, 3), out=db)
         if dw is not None or db is not None:
-            _wgrad(job, ctx.defer_wgrad)
+            _wgrad(job, ctx.defer_wgrad, heavy=True)
         return dx, dw, db
 
 

@@ -7,4 +7,4 @@ timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $R -o tl -- py
 rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo TIMEOUT; exit 1; fi
 tail -c 600 $O/bench.json
 T=$(find $R -name "*kernel_trace.csv" | head -1); echo "trace: $T"; head -2 $T | cut -c1-600
-python3 tools/timeline.py $T $O/timeline.json > $O/timeline.txt 2>&1; cat $O/timeline.txt
+python3 tools/timeline.py $T $O/timeline.json $O/sequence.txt > $O/timeline.txt 2>&1; cat $O/timeline.txt

@@ -120,6 +120,10 @@ def main():
         out["queues"][q] = {"launches": len(lst), "busy_us": b, "gap_median_us": med, "gap_p90_us": p90}
     if len(sys.argv) > 2:
         json.dump(out, open(sys.argv[2], "w"), indent=1)
+    if len(sys.argv) > 3:          # the step's dispatches in start order: offset, duration, queue, name
+        with open(sys.argv[3], "w") as f:
+            for s_, e_, q_, n_ in ev:
+                f.write("%9.1f %7.1f q%s %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, q_, n_))
 
 
 if __name__ == "__main__":
