@@ -306,9 +306,9 @@ int kmu_mix3_bwd_apply(const float* dy, const float* g, const float* s, const fl
 
 /* ------------------------------------------------------------------------------------
  * Tap stacking for DirectionViM's (3,1) / (1,3) projections (KM_UNetV3_SH.py:170-172): x [B,C,H,W] ->
- * out [B,3C,H,W], out[t*C + c](p) = x[c](p + (t-1) e_axis) (zero outside), axis 0 = H, 1 = W; a 3-tap conv along
- * that axis is then kmu_pwconv_* with Ci = 3C and weight W'[co, t*C + ci] = W[co, ci, t].  bwd: dx = sum of the three
- * shifted gradient slices.
+ * out [B,3C,H,W], out[3*c + t](p) = x[c](p + (t-1) e_axis) (zero outside), axis 0 = H, 1 = W; a 3-tap conv along
+ * that axis is then kmu_pwconv_* with Ci = 3C and weight W'[co, 3*ci + t] = W[co, ci, t] -- the convolution's own
+ * [Co,Ci,3,1] / [Co,Ci,1,3] weight read as [Co, 3 Ci], no permuted copy.  bwd: dx = sum of the three shifted gradient slices.
  * ------------------------------------------------------------------------------------ */
 int kmu_shift3_fwd(const float* x, float* out, int B, int C, int H, int W, int axis, kmu_stream_t stream);
 int kmu_shift3_bwd(const float* gout, float* dx, int B, int C, int H, int W, int axis, kmu_stream_t stream);
@@ -553,6 +553,10 @@ int kmu_layernorm1d_fwd_g(const float* x, const float* weight, const float* bias
                           float eps, int groups, kmu_stream_t stream);
 int kmu_layernorm1d_bwd_g(const float* x, const float* weight, const float* rstd_mean, const float* dy, float* dx,
                           float* d_weight_partial, float* d_bias_partial, int B, int C, int L, int groups, kmu_stream_t stream);
+/* kmu_layernorm1d_bwd_g with dx += addend [B,C,L] (NULL: none): the gradient of a second consumer of the normalised tensor --
+ * EfficientViMBlock blends the mixer's output with the x it normalised (efficient_vim_init.py:88-90) -- folded into the kernel. */
+int kmu_layernorm1d_bwd_add(const float* x, const float* weight, const float* rstd_mean, const float* dy, const float* addend, float* dx,
+                            float* d_weight_partial, float* d_bias_partial, int B, int C, int L, int groups, kmu_stream_t stream);
 size_t kmu_hsmssd_fwd_ws_bytes_g(int B, int C, int N, int Hs, int groups);
 int kmu_hsmssd_fwd_stage_x3_g(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
                               const float* D, float* y, float* h, float* state, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,

@@ -117,6 +117,7 @@ SIGNATURES = {
     "kmu_pwconv_bwd_weight_g": (_I, [_P] * 5 + [_Z] + [_I] * 7 + [_P]),
     "kmu_layernorm1d_fwd_g": (_I, [_P] * 5 + [_I] * 3 + [_c.c_float, _I, _P]),
     "kmu_layernorm1d_bwd_g": (_I, [_P] * 7 + [_I] * 4 + [_P]),
+    "kmu_layernorm1d_bwd_add": (_I, [_P] * 8 + [_I] * 4 + [_P]),
     "kmu_hsmssd_fwd_ws_bytes_g": (_Z, [_I] * 5),
     "kmu_hsmssd_fwd_stage_x3_g": (_I, [_P] * 10 + [_Z] + [_I] * 6 + [_P]),
     "kmu_hsmssd_bwd_ws_bytes_x3_g": (_Z, [_I] * 5),

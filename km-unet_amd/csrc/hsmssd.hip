@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void ln1d_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void ln1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ stats, const float* __restrict__ dy,
                                                        float* __restrict__ dx, float* __restrict__ dw_part,
-                                                       float* __restrict__ db_part, int C, int L, int G) {
+                                                       float* __restrict__ db_part, int C, int L, int G,
+                                                       const float* __restrict__ addend) {
     __shared__ float red[2][4];
     const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
     w += (b % G) * C;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void ln1d_bwd_kernel(const float* __restrict__
         if (ok) {
             const float d = dy[base + (size_t)c * L];
             const float xh = (x[base + (size_t)c * L] - mu) * rstd;
-            dx[base + (size_t)c * L] = rstd * (d * w[c] - s1 - xh * s2);
+            dx[base + (size_t)c * L] = rstd * (d * w[c] - s1 - xh * s2) + (addend ? addend[base + (size_t)c * L] : 0.f);
             gdw = d * xh;
             gdb = d;
         }
@@ -566,7 +567,10 @@ template <int C, int V>
 __global__ __launch_bounds__(256) void ln1d_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ stats, const float* __restrict__ dy,
                                                            float* __restrict__ dx, float* __restrict__ dw_part,
-                                                           float* __restrict__ db_part, int L, int G) {
+                                                           float* __restrict__ db_part, int L, int G,
+                                                           const float* __restrict__ addend) {
+    // addend: gradient of a second consumer of x (EfficientViMBlock blends the mixer's output with the x it normalised,
+    // efficient_vim_init.py:88-90) added here instead of in an ATen fan-in launch
     __shared__ float red[2 * C][4];
     const int b = blockIdx.y, l0 = (blockIdx.x * 256 + threadIdx.x) * V;
     w += (b % G) * C;
@@ -607,6 +611,12 @@ __global__ __launch_bounds__(256) void ln1d_bwd_reg_kernel(const float* __restri
             float o[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) o[i] = rstd[i] * (g[c][i] * wc - s1[i] - xh[c][i] * s2[i]);
+            if (addend) {
+                float ad[V];
+                ldv<V>(ad, addend + base + (size_t)c * L);
+#pragma unroll
+                for (int i = 0; i < V; ++i) o[i] += ad[i];
+            }
             stv<V>(dx + base + (size_t)c * L, o);
         }
     }
@@ -810,9 +820,9 @@ extern "C" int kmu_layernorm1d_fwd(const float* x, const float* weight, const fl
     return kmu_layernorm1d_fwd_g(x, weight, bias, y, rstd_mean, B, C, L, eps, 1, stream);
 }
 
-extern "C" int kmu_layernorm1d_bwd_g(const float* x, const float* weight, const float* rstd_mean, const float* dy,
-                                     float* dx, float* d_weight_partial, float* d_bias_partial, int B, int C, int L,
-                                     int groups, kmu_stream_t stream) {
+extern "C" int kmu_layernorm1d_bwd_add(const float* x, const float* weight, const float* rstd_mean, const float* dy, const float* addend,
+                                       float* dx, float* d_weight_partial, float* d_bias_partial, int B, int C, int L,
+                                       int groups, kmu_stream_t stream) {
     KMU_REQUIRE(x && weight && rstd_mean && dy && dx && d_weight_partial && d_bias_partial, "layernorm1d_bwd: null pointer");
     KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0 && groups >= 1 && B % groups == 0, "layernorm1d_bwd: bad dims");
     const int G = groups;
@@ -821,17 +831,23 @@ extern "C" int kmu_layernorm1d_bwd_g(const float* x, const float* weight, const 
     const dim3 grid(kmu::cdiv(L, 256 * (V ? V : 1)), B);
     if (C == 16 && V == 2)
         hipLaunchKernelGGL((ln1d_bwd_reg_kernel<16, 2>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
-                           d_bias_partial, L, G);
+                           d_bias_partial, L, G, addend);
     else if (C == 32 && V == 1)
         hipLaunchKernelGGL((ln1d_bwd_reg_kernel<32, 1>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
-                           d_bias_partial, L, G);
+                           d_bias_partial, L, G, addend);
     else if (C == 64 && V == 1)
         hipLaunchKernelGGL((ln1d_bwd_reg_kernel<64, 1>), grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial,
-                           d_bias_partial, L, G);
+                           d_bias_partial, L, G, addend);
     else
         hipLaunchKernelGGL(ln1d_bwd_kernel, grid, dim3(256), 0, st, x, weight, rstd_mean, dy, dx, d_weight_partial, d_bias_partial, C,
-                           L, G);
+                           L, G, addend);
     return kmu::launch_status("layernorm1d_bwd");
+}
+
+extern "C" int kmu_layernorm1d_bwd_g(const float* x, const float* weight, const float* rstd_mean, const float* dy,
+                                     float* dx, float* d_weight_partial, float* d_bias_partial, int B, int C, int L,
+                                     int groups, kmu_stream_t stream) {
+    return kmu_layernorm1d_bwd_add(x, weight, rstd_mean, dy, nullptr, dx, d_weight_partial, d_bias_partial, B, C, L, groups, stream);
 }
 
 extern "C" int kmu_layernorm1d_bwd(const float* x, const float* weight, const float* rstd_mean, const float* dy,

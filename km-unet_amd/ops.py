@@ -652,8 +652,9 @@ class LayerNorm1dFn(torch.autograd.Function):
     """Per-token LayerNorm over C of [B,C,L] (vim_utils_init.py:50-59)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, alias=False):
         lib = _lib.load()
+        xin = x
         x = _f32c(x, "x")
         w, b = _f32c(weight, "weight").reshape(-1), _f32c(bias, "bias").reshape(-1)
         B, C, L = x.shape
@@ -664,27 +665,40 @@ class LayerNorm1dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, stats)
         ctx.wshape = weight.shape
         ctx.defer_wgrad = _leaf(weight, bias)
+        if alias:      # second output: x itself, for a second consumer whose gradient the backward kernel adds in (no fan-in launch)
+            ctx.set_materialize_grads(False)
+            return y, xin.view_as(xin)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         lib = _lib.load()
         x, w, stats = ctx.saved_tensors
-        dy = _f32c(dy, "dy")
         B, C, L = x.shape
+        if dy is None:                   # only the alias was used
+            return dalias, None, None, None, None
+        dy = _f32c(dy, "dy")
+        addend = None if dalias is None else _f32c(dalias, "grad of the alias")
         rows = lib.kmu_layernorm1d_partials(B, C, L)
         dx = torch.empty_like(x)
         dwp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
         dbp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
-        _lib.check(lib.kmu_layernorm1d_bwd(_ptr(x), _ptr(w), _ptr(stats), _ptr(dy), _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, L,
-                                           _stream()), "kmu_layernorm1d_bwd")
+        _lib.check(lib.kmu_layernorm1d_bwd_add(_ptr(x), _ptr(w), _ptr(stats), _ptr(dy), _ptr(addend), _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, L,
+                                               1, _stream()), "kmu_layernorm1d_bwd_add")
         dw, db = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
         _wgrad(lambda: colsum(dwp, dbp, outs=[dw, db]), ctx.defer_wgrad)
-        return dx, dw.view(ctx.wshape), db.view(ctx.wshape), None
+        return dx, dw.view(ctx.wshape), db.view(ctx.wshape), None, None
 
 
 def layernorm1d(x, weight, bias, eps=1e-5):
     return LayerNorm1dFn.apply(x, weight, bias, eps)
+
+
+def layernorm1d_alias(x, weight, bias, eps=1e-5):
+    """(LayerNorm(x), x'): x' aliases x; its gradient is added inside the LayerNorm backward kernel."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return LayerNorm1dFn.apply(x, weight, bias, eps), x
+    return LayerNorm1dFn.apply(x, weight, bias, eps, True)
 
 
 def _hsm_pack(ok, w_bcdt, w_dw, C, st):
@@ -1025,9 +1039,9 @@ class Shift3Fn(torch.autograd.Function):
 def conv3tap(x, weight, bias, axis):
     """nn.Conv2d with a (3,1) (axis 0) or (1,3) (axis 1) kernel, stride 1, padding 1 on that axis (KM_UNetV3_SH.py:170-172):
     tap stacking + the pointwise-conv kernels."""
-    co, ci = weight.shape[:2]
-    w2 = weight.reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci)      # W'[co, t*Ci + ci] = W[co, ci, t]
-    return pwconv(Shift3Fn.apply(x, axis), w2, bias)
+    # channel-major tap order: the stacked input's channel 3 ci + t pairs with W[co, ci, t] -- the weight tensor itself, read as
+    # [Co, 3 Ci] inside PwConvFn (no permuted copy, the Parameter stays a leaf: its gradient is deferred like any other)
+    return pwconv(Shift3Fn.apply(x, axis), weight, bias)
 
 
 # ------------------------------------------------------------------------------------------ branch fusion
@@ -1835,7 +1849,10 @@ class PwConvFn(torch.autograd.Function):
         ctx.defer_wgrad = _leaf(weight, bias)
         lib = _lib.load()
         x = _f32c(x, "x")
-        co, ci = weight.shape[:2]
+        co = weight.shape[0]
+        ci = weight.numel() // co              # [Co, Ci, 1, 1], [Co, Ci] or a 3-tap kernel [Co, Ci/3, 3, 1] over stacked taps
+        if x.shape[1] != ci:
+            raise RuntimeError("pwconv: weight %s does not contract the %d input channels" % (tuple(weight.shape), x.shape[1]))
         w = _f32c(weight, "weight").view(co, ci)
         B, _, H, W = x.shape
         y = torch.empty(B, co, H, W, device=x.device, dtype=torch.float32)

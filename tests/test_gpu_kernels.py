@@ -795,6 +795,27 @@ def test_spatial_mean_vs_torch_cpu(B, C, H, W):
     _report("spatial_mean %s" % ((B, C, H, W),), y=rel_err(m, x.mean(dim=(2, 3))), dx=rel_err(xd.grad, x.grad))
 
 
+@pytest.mark.parametrize("B,C,L", [(2, 16, 1024), (8, 32, 4096), (3, 64, 256), (2, 24, 100)])
+def test_layernorm1d_alias_vs_torch_cpu(B, C, L):
+    """LayerNorm1D (vim_utils_init.py:50-59) with a second consumer of its input served by an alias output: the alias' gradient
+    is added inside the backward kernel (EfficientViMBlock's blend partner, efficient_vim_init.py:88-90)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C + L)
+    x = torch.randn(B, C, L, generator=gen, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(1, C, 1, generator=gen, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(1, C, 1, generator=gen, dtype=torch.float64).requires_grad_(True)
+    gy, ga = torch.randn(B, C, L, generator=gen, dtype=torch.float64), torch.randn(B, C, L, generator=gen, dtype=torch.float64)
+    mu, var = x.mean(1, keepdim=True), x.var(1, keepdim=True, unbiased=False)
+    y = (x - mu) / torch.sqrt(var + 1e-5) * w + b
+    ((y * gy).sum() + (x * x * ga).sum()).backward()
+    xd, wd, bd = (t.detach().float().to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd, xa = ops.layernorm1d_alias(xd, wd, bd, 1e-5)
+    assert xa.data_ptr() == xd.data_ptr()
+    ((yd * gy.float().to(DEV)).sum() + (xa * xa * ga.float().to(DEV)).sum()).backward()
+    _report("layernorm1d_alias %s" % ((B, C, L),), y=rel_err(yd, y), dx=rel_err(xd.grad, x.grad), dw=rel_err(wd.grad, w.grad),
+            db=rel_err(bd.grad, b.grad))
+
+
 @pytest.mark.parametrize("B,C,H,W,use", [(2, 16, 32, 32, "both"), (8, 32, 64, 64, "both"), (3, 64, 8, 16, "both"), (2, 16, 16, 16, "conv"),
                                          (2, 16, 16, 16, "mean")])
 def test_mean_pwconv_vs_torch_cpu(B, C, H, W, use):
