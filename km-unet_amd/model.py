@@ -29,9 +29,11 @@ _BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") == "1"
 # serialised kernel time per step -- but 13.5 ms/step against 12.9 for the forked branches (grouped only at C >= 32: 13.0, C >= 64:
 # 12.96): the stacked kernels fill the device, so the weight-gradient / pyramid side streams no longer find idle CUs to overlap
 # into, while the three forked branches already overlap each other well.  Kept as a tested option (a single-stream runtime, or a
-# larger batch where the forks stop paying, would prefer it); off by default.
-_GROUPED_BRANCHES = _os.environ.get("KMU_GROUPED_BRANCHES", "0") == "1"
-_GROUPED_MIN_C = int(_os.environ.get("KMU_GROUPED_MIN_C", "0"))
+# larger batch where the forks stop paying, would prefer it).
+# Round 3: on by default from C = 64 up (the 32x32 level, whose per-branch kernels are far too small for 256 CUs): 9.99 -> 9.77 ms
+# per step; at C = 32 the stacked pass (which predates the fused FFN / dwconv-BN kernels) still loses: 10.49.
+_GROUPED_BRANCHES = _os.environ.get("KMU_GROUPED_BRANCHES", "1") == "1"
+_GROUPED_MIN_C = int(_os.environ.get("KMU_GROUPED_MIN_C", "64"))
 _SIDE = {}
 
 
