@@ -647,6 +647,11 @@ int kmu_bn_blend_bwd_partials(const float* gout, const float* t, const float* x,
 int kmu_dwconv3x3_bn_bwd_data(const float* g, const float* t, const float* weight, const float* gamma, const float* alpha, const float* stats,
                               const float* part, int S, int training, float* dx, float* d_gamma, float* d_beta, float* d_alpha, float* cst,
                               int B, int C, int H, int W, kmu_stream_t stream);
+/* both of them in one launch (round 3): dx, the BatchNorm / blend parameter gradients AND the weight-gradient partials from one pass
+ * over (g, t, x); results bit-identical to the two-kernel path */
+int kmu_dwconv3x3_bn_bwd_all(const float* g, const float* t, const float* x, const float* weight, const float* gamma, const float* alpha,
+                             const float* stats, const float* part, int S, int training, float* dx, float* d_gamma, float* d_beta,
+                             float* d_alpha, float* d_weight_partial, int B, int C, int H, int W, kmu_stream_t stream);
 int kmu_dwconv3x3_bn_bwd_weight(const float* x, const float* g, const float* t, const float* cst, float* d_weight_partial, int B, int C,
                                 int H, int W, kmu_stream_t stream);
 

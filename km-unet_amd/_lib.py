@@ -164,6 +164,7 @@ SIGNATURES = {
     "kmu_bn_blend_bwd_partials": (_I, [_P] * 7 + [_I, _P] + [_I] * 3 + [_P]),
     "kmu_dwconv3x3_bn_bwd_data": (_I, [_P] * 7 + [_I, _I] + [_P] * 5 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_bn_bwd_weight": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "kmu_dwconv3x3_bn_bwd_all": (_I, [_P] * 8 + [_I, _I] + [_P] * 5 + [_I] * 4 + [_P]),
     "kmu_tail_ffn_fwd": (_I, [_P] * 8 + [_I] * 3 + [_P]),
     "kmu_tail_ffn_bwd": (_I, [_P] * 10 + [_I] * 3 + [_P]),
     "kmu_contingency_counts": (_I, [_P] * 3 + [_Z, _P, _I, _c.c_float, _P]),

@@ -332,6 +332,104 @@ __global__ __launch_bounds__(256) void dwconv3x3_bn_bwd_weight_kernel(const floa
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// Both of the above in one pass: a workgroup owns the rows [y0, y1) of one (b, c) plane (the weight kernel's decomposition), forms dt
+// once per strip, applies the transposed stencil for dx AND accumulates the 9 weight-gradient taps against x.  The separate
+// weight-gradient launch re-read g and t to rebuild dt (31 launches and ~0.3 ms of kernel time per step in the backward's tail);
+// here it costs the x rows on top of the data-gradient pass.  Same arithmetic, same order: dx and the partials are bit-identical
+// to the two-kernel path.
+__global__ __launch_bounds__(256) void dwconv3x3_bn_bwd_all_kernel(const float* __restrict__ g, const float* __restrict__ t,
+                                                                   const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ alpha,
+                                                                   const float* __restrict__ stats, const float* __restrict__ part, int S,
+                                                                   int training, double N, float* __restrict__ dx,
+                                                                   float* __restrict__ d_gamma, float* __restrict__ d_beta,
+                                                                   float* __restrict__ d_alpha, float* __restrict__ dw_part, int C, int H,
+                                                                   int W) {
+    __shared__ float red[4][9];
+    const int c = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    // the channel's folded BatchNorm-backward partials (uniform over the workgroup: scalar loads, fixed order, double)
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    for (int i = 0; i < S; ++i) {
+        const float* p = part + ((size_t)c * S + i) * 3;
+        q0 += p[0], q1 += p[1], q2 += p[2];
+    }
+    floatx4 k;
+    {
+        const float mean = stats[2 * c], rstd = stats[2 * c + 1], a = 1.f / (1.f + __expf(-alpha[c]));
+        const float kk = gamma[c] * rstd;
+        const float m0 = training ? (float)(q0 / N) : 0.f, m1 = training ? (float)(q1 / N) : 0.f;
+        k = floatx4{kk * a, -kk * m1 * rstd, kk * (m1 * rstd * mean - m0), 1.f - a};
+        if (b == 0 && sp == 0 && threadIdx.x == 0) {
+            d_gamma[c] = (float)q1;
+            d_beta[c] = (float)q0;
+            d_alpha[c] = (float)q2 * a * (1.f - a);
+        }
+    }
+    float wv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wv[i] = w[c * 9 + 8 - i];       // transposed stencil: flipped taps
+    const int rows = (H + WSPLIT - 1) / WSPLIT, y0 = sp * rows, y1 = min(H, y0 + rows);
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* xp = x + plane;
+    float wacc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wacc[i] = 0.f;
+    const int W4 = W >> 2, nstrip = max(0, y1 - y0) * W4;
+    for (int sidx = threadIdx.x; sidx < nstrip; sidx += 256) {
+        const int y = y0 + sidx / W4, x0 = (sidx % W4) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        floatx4 gc = {0.f, 0.f, 0.f, 0.f};
+        float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const size_t o = plane + (size_t)yy * W + x0;
+            const floatx4 gm = *reinterpret_cast<const floatx4*>(g + o), tm = *reinterpret_cast<const floatx4*>(t + o);
+            float v[6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[1 + i] = fmaf(k[0], gm[i], fmaf(k[1], tm[i], k[2]));
+            v[0] = x0 > 0 ? fmaf(k[0], g[o - 1], fmaf(k[1], t[o - 1], k[2])) : 0.f;
+            v[5] = x0 + 4 < W ? fmaf(k[0], g[o + 4], fmaf(k[1], t[o + 4], k[2])) : 0.f;
+            if (dy == 1) {
+                gc = gm;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g4[i] = v[1 + i];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int dxx = 0; dxx < 3; ++dxx) acc[q] += wv[dy * 3 + dxx] * v[q + dxx];
+        }
+        // weight gradient: dt of this strip's 4 pixels (the centre row's, g4) against x on the three rows around it
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+            const int yy = y + dyy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float* row = xp + (size_t)yy * W;
+            const floatx4 m = *reinterpret_cast<const floatx4*>(row + x0);
+            const float v[6] = {x0 > 0 ? row[x0 - 1] : 0.f, m[0], m[1], m[2], m[3], x0 + 4 < W ? row[x0 + 4] : 0.f};
+#pragma unroll
+            for (int dxx = 0; dxx < 3; ++dxx)
+                wacc[dyy * 3 + dxx] += (g4[0] * v[dxx] + g4[1] * v[dxx + 1]) + (g4[2] * v[dxx + 2] + g4[3] * v[dxx + 3]);
+        }
+        floatx4 o4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o4[q] = fmaf(k[3], gc[q], acc[q]);
+        *reinterpret_cast<floatx4*>(dx + plane + (size_t)y * W + x0) = o4;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float s_ = kmu::wave_sum(wacc[i]);
+        if (lane == 0) red[wave][i] = s_;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        dw_part[(((size_t)b * WSPLIT + sp) * C + c) * 9 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 int launch_stencil(const float* in, const float* w, const float* bias, const float* scale, float* out, int B, int C, int H, int W,
                    int flip, hipStream_t st, const char* what, const float* addend = nullptr) {
     const size_t total = (size_t)B * C * H * ((W + 3) / 4);
@@ -434,6 +532,20 @@ extern "C" int kmu_dwconv3x3_bn_bwd_data(const float* g, const float* t, const f
     hipLaunchKernelGGL(dwconv3x3_bn_bwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * 16, (hipStream_t)stream, g, t, weight, gamma, alpha,
                        stats, part, S, training, (double)B * H * W, dx, d_gamma, d_beta, d_alpha, cst, C, H, W, total);
     return kmu::launch_status("dwconv3x3_bn_bwd_data");
+}
+
+// kmu_dwconv3x3_bn_bwd_data and kmu_dwconv3x3_bn_bwd_weight in ONE launch (x: the stage's input; d_weight_partial as the weight
+// entry point leaves it): the weight-gradient job behind it shrinks to the column sum of the partials
+extern "C" int kmu_dwconv3x3_bn_bwd_all(const float* g, const float* t, const float* x, const float* weight, const float* gamma,
+                                        const float* alpha, const float* stats, const float* part, int S, int training, float* dx,
+                                        float* d_gamma, float* d_beta, float* d_alpha, float* d_weight_partial, int B, int C, int H, int W,
+                                        kmu_stream_t stream) {
+    KMU_REQUIRE(g && t && x && weight && gamma && alpha && stats && part && dx && d_gamma && d_beta && d_alpha && d_weight_partial,
+                "dwconv3x3_bn_bwd_all: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && W % 4 == 0 && S > 0, "dwconv3x3_bn_bwd_all: bad dims (W %% 4 == 0 required)");
+    hipLaunchKernelGGL(dwconv3x3_bn_bwd_all_kernel, dim3(C, B, WSPLIT), dim3(256), 0, (hipStream_t)stream, g, t, x, weight, gamma, alpha, stats,
+                       part, S, training, (double)B * H * W, dx, d_gamma, d_beta, d_alpha, d_weight_partial, C, H, W);
+    return kmu::launch_status("dwconv3x3_bn_bwd_all");
 }
 
 extern "C" int kmu_dwconv3x3_bn_bwd_weight(const float* x, const float* g, const float* t, const float* cst, float* d_weight_partial, int B,

@@ -1640,6 +1640,15 @@ class DwBnBlendFn(torch.autograd.Function):
                              _ptr(beta), _ptr(a_row), _ptr(stats), 0, _ptr(part), B, C, H * W, st), "kmu_bn_blend_bwd_partials")
             dx = torch.empty_like(x)
             dg, db, da = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(3))
+            if DWBN_ALL and B <= 65535:
+                # ... and the weight-gradient taps from the same pass: the deferred job is only the column sum of the partials
+                dwp = torch.empty(lib.kmu_dwconv3x3_partials(B), C, 9, device=dev, dtype=torch.float32)
+                _lib.check(_call(("dwconv3x3_bn_bwd_all", (B, C, H, W)), lib.kmu_dwconv3x3_bn_bwd_all, _ptr(g), _ptr(t), _ptr(x), _ptr(w),
+                                 _ptr(gamma), _ptr(a_row), _ptr(stats), _ptr(part), S, training, _ptr(dx), _ptr(dg), _ptr(db), _ptr(da),
+                                 _ptr(dwp), B, C, H, W, st), "kmu_dwconv3x3_bn_bwd_all")
+                dw = torch.empty(C, 9, device=dev, dtype=torch.float32)
+                _wgrad(lambda: colsum(dwp, outs=[dw]), ctx.defer_wgrad)
+                return dx, dw.view(wshape), dg, db, da, None, None, None, None, None, None
             cst = torch.empty(C, 4, device=dev, dtype=torch.float32)
             _lib.check(_call(("dwconv3x3_bn_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_bn_bwd_data, _ptr(g), _ptr(t), _ptr(w), _ptr(gamma),
                              _ptr(a_row), _ptr(stats), _ptr(part), S, training, _ptr(dx), _ptr(dg), _ptr(db), _ptr(da), _ptr(cst), B, C, H, W,
@@ -1714,6 +1723,7 @@ class FfnBlendFn(torch.autograd.Function):
 FFN_FUSED = os.environ.get("KMU_FFN_FUSED", "1") == "1"
 TAIL_FUSED = os.environ.get("KMU_TAIL_FUSED", "1") == "1"      # EnhancedViMBlock's tail FFN as one recompute launch each way
 DWBN_FUSED = os.environ.get("KMU_DWBN_FUSED", "1") == "1"      # dwconv stage backward: BatchNorm folded into the transposed stencil
+DWBN_ALL = os.environ.get("KMU_DWBN_ALL", "1") == "1"          # ... and the weight-gradient taps taken in the same launch
 _FFN_STAGES_F = ("ffn_fwd_stats", "ffn_fwd_main", "ffn_fwd_apply")
 _FFN_STAGES_B = ("ffn_bwd_red", "ffn_bwd_mid", "ffn_bwd_in")
 

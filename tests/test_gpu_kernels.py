@@ -1003,6 +1003,30 @@ def test_dw_bn_blend_vs_torch_cpu(B, C, H, W, train):
             dw=rel_err(cd.weight.grad, cr.weight.grad), dgamma=rel_err(bd.weight.grad, br.weight.grad), dbeta=rel_err(bd.bias.grad, br.bias.grad),
             rmean=rel_err(bd.running_mean, br.running_mean), rvar=rel_err(bd.running_var, br.running_var))
 
+@pytest.mark.parametrize("B,C,H,W", [(8, 16, 128, 128), (2, 32, 16, 16), (3, 64, 8, 12), (2, 16, 6, 4)])
+def test_dw_bn_blend_one_launch_backward_is_bit_identical(monkeypatch, B, C, H, W):
+    """kmu_dwconv3x3_bn_bwd_all (dx, BatchNorm / blend gradients and the weight-gradient partials in one pass) against the two-kernel
+    path it replaces: the same arithmetic in the same order, so every gradient must be bit-identical."""
+    import torch.nn as nn
+    ops = _ops()
+    gen = torch.Generator().manual_seed(7 * C + H)
+    conv = nn.Conv2d(C, C, 3, padding=1, groups=C, bias=False).to(DEV)
+    bn = nn.BatchNorm2d(C).to(DEV).train()
+    alpha = torch.randn(C, generator=gen).to(DEV).requires_grad_(True)
+    x = (torch.randn(B, C, H, W, generator=gen) * 1.5 + 0.3).to(DEV)
+    gy = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "DWBN_ALL", flag)
+        xd = x.clone().requires_grad_(True)
+        ops.dw_bn_blend(xd, conv, bn, alpha).backward(gy)
+        res.append([t.grad.clone() for t in (xd, alpha, conv.weight, bn.weight, bn.bias)])
+        for t in (alpha, conv.weight, bn.weight, bn.bias):
+            t.grad = None
+    for a, b, name in zip(res[0], res[1], ("dx", "dalpha", "dw", "dgamma", "dbeta")):
+        assert torch.equal(a, b), name
+
+
 # ------------------------------------------------------------------------------------------ blocks
 @pytest.mark.parametrize("name,train", [("evim_eval", False), ("evim_train", True)])
 def test_evim_block_golden(name, train):
