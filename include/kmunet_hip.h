@@ -265,6 +265,9 @@ int kmu_dwconv3x3_scaled_fwd(const float* x, const float* weight, const float* b
                              int H, int W, kmu_stream_t stream);
 int kmu_dwconv3x3_scaled_bwd_data(const float* dy, const float* weight, const float* scale, float* dx, int B, int C, int H, int W,
                                   kmu_stream_t stream);
+/* kmu_dwconv3x3_scaled_bwd_data and kmu_dwconv3x3_bwd_weight (with bias partials) in one launch, W % 4 == 0 (KM_UNetV3_SH.py:262-263) */
+int kmu_dwconv3x3_scaled_bwd_all(const float* dy, const float* x, const float* weight, const float* scale, float* dx,
+                                 float* d_weight_partial, float* d_bias_partial, int B, int C, int H, int W, kmu_stream_t stream);
 int kmu_dwconv3x3_scaled_finish(const float* d_weight_partial, const float* d_bias_partial, const float* scale,
                                 const float* weight, const float* bias, float* d_weight, float* d_bias, float* d_scale, int B,
                                 int C, kmu_stream_t stream);

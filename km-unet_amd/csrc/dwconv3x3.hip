@@ -430,6 +430,72 @@ __global__ __launch_bounds__(256) void dwconv3x3_bn_bwd_all_kernel(const float* 
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// DirectionAttention's scaled stencil backward (KM_UNetV3_SH.py:262-263) in one pass: dx = s[b,c] dwconv^T(dy) and the (b, row-split,
+// c) partials of the weight-gradient kernel (A[t] = sum dy x_shift_t, G = sum dy) -- the two launches read dy twice and sat back to
+// back on the branch's backward chain (the gate gradient d s needs the partials before the chain can go on).  W % 4 == 0.
+__global__ __launch_bounds__(256) void dwconv3x3_scaled_bwd_all_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                       const float* __restrict__ w, const float* __restrict__ scale,
+                                                                       float* __restrict__ dx, float* __restrict__ dw_part,
+                                                                       float* __restrict__ db_part, int C, int H, int W) {
+    __shared__ float red[4][10];
+    const int c = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int rows = (H + WSPLIT - 1) / WSPLIT, y0 = sp * rows, y1 = min(H, y0 + rows);
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* xp = x + plane;
+    const float* gp = dy + plane;
+    const float sc = scale[b * C + c];
+    float wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = w[c * 9 + 8 - k];
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    const int W4 = W >> 2, nstrip = max(0, y1 - y0) * W4;
+    for (int sidx = threadIdx.x; sidx < nstrip; sidx += 256) {
+        const int y = y0 + sidx / W4, x0 = (sidx % W4) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+            const int yy = y + dyy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float* row = gp + (size_t)yy * W;
+            const floatx4 m = *reinterpret_cast<const floatx4*>(row + x0);
+            const float v[6] = {x0 > 0 ? row[x0 - 1] : 0.f, m[0], m[1], m[2], m[3], x0 + 4 < W ? row[x0 + 4] : 0.f};
+            if (dyy == 1) g4[0] = m[0], g4[1] = m[1], g4[2] = m[2], g4[3] = m[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int dxx = 0; dxx < 3; ++dxx) o[q] += wv[dyy * 3 + dxx] * v[q + dxx];
+        }
+        *reinterpret_cast<floatx4*>(dx + plane + (size_t)y * W + x0) = floatx4{o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc};
+        acc[9] += (g4[0] + g4[1]) + (g4[2] + g4[3]);
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+            const int yy = y + dyy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float* row = xp + (size_t)yy * W;
+            const floatx4 m = *reinterpret_cast<const floatx4*>(row + x0);
+            const float v[6] = {x0 > 0 ? row[x0 - 1] : 0.f, m[0], m[1], m[2], m[3], x0 + 4 < W ? row[x0 + 4] : 0.f};
+#pragma unroll
+            for (int dxx = 0; dxx < 3; ++dxx)
+                acc[dyy * 3 + dxx] += (g4[0] * v[dxx] + g4[1] * v[dxx + 1]) + (g4[2] * v[dxx + 2] + g4[3] * v[dxx + 3]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float s_ = kmu::wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s_;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float s_ = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const size_t prow = (size_t)b * WSPLIT + sp;
+        if (threadIdx.x < 9) dw_part[(prow * C + c) * 9 + threadIdx.x] = s_;
+        else db_part[prow * C + c] = s_;
+    }
+}
+
 int launch_stencil(const float* in, const float* w, const float* bias, const float* scale, float* out, int B, int C, int H, int W,
                    int flip, hipStream_t st, const char* what, const float* addend = nullptr) {
     const size_t total = (size_t)B * C * H * ((W + 3) / 4);
@@ -496,6 +562,16 @@ extern "C" int kmu_dwconv3x3_scaled_bwd_data(const float* dy, const float* weigh
     KMU_REQUIRE(dy && weight && scale && dx, "dwconv3x3_scaled_bwd_data: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_scaled_bwd_data: bad dims");
     return launch_stencil(dy, weight, nullptr, scale, dx, B, C, H, W, 1, (hipStream_t)stream, "dwconv3x3_scaled_bwd_data");
+}
+
+// kmu_dwconv3x3_scaled_bwd_data + kmu_dwconv3x3_bwd_weight in one launch (W % 4 == 0); partials as the weight entry point leaves them
+extern "C" int kmu_dwconv3x3_scaled_bwd_all(const float* dy, const float* x, const float* weight, const float* scale, float* dx,
+                                            float* d_weight_partial, float* d_bias_partial, int B, int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && x && weight && scale && dx && d_weight_partial && d_bias_partial, "dwconv3x3_scaled_bwd_all: null pointer");
+    KMU_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && W % 4 == 0, "dwconv3x3_scaled_bwd_all: bad dims (W %% 4 == 0 required)");
+    hipLaunchKernelGGL(dwconv3x3_scaled_bwd_all_kernel, dim3(C, B, WSPLIT), dim3(256), 0, (hipStream_t)stream, dy, x, weight, scale, dx,
+                       d_weight_partial, d_bias_partial, C, H, W);
+    return kmu::launch_status("dwconv3x3_scaled_bwd_all");
 }
 
 extern "C" int kmu_dwconv3x3_scaled_finish(const float* d_weight_partial, const float* d_bias_partial, const float* scale,

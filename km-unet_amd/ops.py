@@ -991,15 +991,20 @@ class DwConv3x3ScaledFn(torch.autograd.Function):
         B, C, H, W = x.shape
         st, dev = _stream(), x.device
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            _lib.check(_call(("dwconv3x3_scaled_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_scaled_bwd_data, _ptr(dy), _ptr(w), _ptr(sc),
-                             _ptr(dx), B, C, H, W, st), "kmu_dwconv3x3_scaled_bwd_data")
         P = lib.kmu_dwconv3x3_partials(B)
         dwp = torch.empty(P, C, 9, device=dev, dtype=torch.float32)
         dbp = torch.empty(P, C, device=dev, dtype=torch.float32)
-        _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dy), _ptr(dwp), _ptr(dbp), B, C,
-                         H, W, st), "kmu_dwconv3x3_bwd_weight")
+        if ctx.needs_input_grad[0] and DWBN_ALL and W % 4 == 0 and B <= 65535:      # data gradient and partials from one pass over dy
+            dx = torch.empty_like(x)
+            _lib.check(_call(("dwconv3x3_scaled_bwd_all", (B, C, H, W)), lib.kmu_dwconv3x3_scaled_bwd_all, _ptr(dy), _ptr(x), _ptr(w), _ptr(sc),
+                             _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, H, W, st), "kmu_dwconv3x3_scaled_bwd_all")
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(_call(("dwconv3x3_scaled_bwd_data", (B, C, H, W)), lib.kmu_dwconv3x3_scaled_bwd_data, _ptr(dy), _ptr(w), _ptr(sc),
+                                 _ptr(dx), B, C, H, W, st), "kmu_dwconv3x3_scaled_bwd_data")
+            _lib.check(_call(("dwconv3x3_bwd_weight", (B, C, H, W)), lib.kmu_dwconv3x3_bwd_weight, _ptr(x), _ptr(dy), _ptr(dwp), _ptr(dbp), B, C,
+                             H, W, st), "kmu_dwconv3x3_bwd_weight")
         dw = torch.empty(C, 1, 3, 3, device=dev, dtype=torch.float32)
         db = torch.empty(C, device=dev, dtype=torch.float32) if b is not None else None
         ds = torch.empty(B, C, device=dev, dtype=torch.float32)
