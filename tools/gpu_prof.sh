@@ -11,7 +11,7 @@ run 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -o $TAG
 tail -3 $O/bench_prof.err
 ST=$(find $R/stats -name "*kernel_stats.csv" | head -1); echo "stats: $ST"
 cp $ST $O/${TAG}_bench_n1_graph_kernel_stats.csv
-python3 tools/profile_summary.py $ST 24 70 > $O/summary.txt 2>&1; head -75 $O/summary.txt
+python3 tools/profile_summary.py $ST 29 70 > $O/summary.txt 2>&1; head -75 $O/summary.txt
 run 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_f -o f -- python3 tools/run_dominant_kernel.py 3 > $O/pmc_f.log 2>&1
 run 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc_w -o w -- python3 tools/run_dominant_kernel.py 3 > $O/pmc_w.log 2>&1
 run 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $R/pmc_sq -o sq -- python3 tools/run_dominant_kernel.py 3 > $O/pmc_sq.log 2>&1
