@@ -135,6 +135,9 @@ def _kernel_model(name, shape):
     if name.startswith("bn_blend_bwd_partials"):
         B, C, HW = shape
         return "hbm", 0.0, t * B * C * HW * 3
+    if name.startswith("qkv_dw_scaled"):       # qkv [B,3C,H,W] read once (+ dy), out / dqkv written once
+        B, C, H, W = shape
+        return "hbm", 60.0 * B * C * H * W, t * B * C * H * W * (4 if name.endswith("fwd") else 7)
     if name.startswith("dwconv3x3_bn_bwd"):
         B, C, H, W = shape
         return "hbm", 24.0 * B * C * H * W, t * B * C * H * W * 3

@@ -265,6 +265,15 @@ int kmu_dwconv3x3_scaled_fwd(const float* x, const float* weight, const float* b
                              int H, int W, kmu_stream_t stream);
 int kmu_dwconv3x3_scaled_bwd_data(const float* dy, const float* weight, const float* scale, float* dx, int B, int C, int H, int W,
                                   kmu_stream_t stream);
+/* DirectionAttention's local gate folded into its stencil (KM_UNetV3_SH.py:258-263; round 3):
+ *     out = s[b,c] * (dwconv3x3(sigmoid(q k) v) + bias),   q, k, v = the three C-channel chunks of qkv [B,3C,H,W],  W % 4 == 0.
+ * The attn tensor is formed on the fly at the stencil's taps (never stored).  bwd: dqkv [B,3C,H,W] and the weight / bias partials
+ * [kmu_dwconv3x3_partials(B)][C][9] / [..][C] that kmu_dwconv3x3_scaled_finish turns into d weight, d bias and d s. */
+int kmu_qkv_dw_scaled_supported(int B, int C, int H, int W);      /* W % 4 == 0 and the per-workgroup attn tile fits 64 KB of LDS */
+int kmu_qkv_dw_scaled_fwd(const float* qkv, const float* weight, const float* bias, const float* scale, float* out, int B, int C, int H,
+                          int W, kmu_stream_t stream);
+int kmu_qkv_dw_scaled_bwd(const float* dy, const float* qkv, const float* weight, const float* scale, float* dqkv, float* d_weight_partial,
+                          float* d_bias_partial, int B, int C, int H, int W, kmu_stream_t stream);
 /* kmu_dwconv3x3_scaled_bwd_data and kmu_dwconv3x3_bwd_weight (with bias partials) in one launch, W % 4 == 0 (KM_UNetV3_SH.py:262-263) */
 int kmu_dwconv3x3_scaled_bwd_all(const float* dy, const float* x, const float* weight, const float* scale, float* dx,
                                  float* d_weight_partial, float* d_bias_partial, int B, int C, int H, int W, kmu_stream_t stream);

@@ -61,6 +61,9 @@ SIGNATURES = {
     "kmu_dwconv3x3_scaled_bwd_data": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_scaled_finish": (_I, [_P] * 8 + [_I] * 2 + [_P]),
     "kmu_dwconv3x3_scaled_bwd_all": (_I, [_P] * 7 + [_I] * 4 + [_P]),
+    "kmu_qkv_dw_scaled_supported": (_I, [_I] * 4),
+    "kmu_qkv_dw_scaled_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "kmu_qkv_dw_scaled_bwd": (_I, [_P] * 7 + [_I] * 4 + [_P]),
     "kmu_gauss11_filter": (_I, [_P] * 3 + [_I] * 4 + [_P]),
     "kmu_mix3_blocks": (_I, [_I]),
     "kmu_mix3_fwd": (_I, [_P] * 7 + [_I] * 2 + [_P]),

@@ -496,6 +496,157 @@ __global__ __launch_bounds__(256) void dwconv3x3_scaled_bwd_all_kernel(const flo
     }
 }
 
+// ---- DirectionAttention's local gate folded into its stencil (KM_UNetV3_SH.py:258-263):
+//        attn = sigmoid(q k) v     (q, k, v = the three C-channel chunks of the packed qkv tensor [B,3C,H,W])
+//        out  = s[b,c] (dwconv3x3(attn) + bias)
+// attn is formed on the fly at the stencil's 18 taps -- the [B,C,H,W] attn tensor is neither written nor re-read (forward: 4 passes
+// instead of 6; backward: 7 instead of 10), and two launches per DirectionAttention and direction leave the branch chains.
+__device__ __forceinline__ float attn_of(float q, float k, float v) { return v / (1.f + __expf(-q * k)); }     // as qkv_gate_fwd_kernel
+
+// A workgroup owns the rows [y0, y1) of one (b, c) plane (the weight-gradient kernels' decomposition) and first builds the attn tile
+// of those rows + one halo row either side in LDS -- every attn value is evaluated ONCE (one exp + one division), not once per tap
+// (the first version recomputed it at all 18 taps of a strip and was no faster than the two kernels it replaced).
+// Tile layout: LA[(row + 1) * S + 4 + x], S = W + 8: four zero columns either side so that a strip's x0 - 1 and x0 + 4 need no test.
+__device__ __forceinline__ void stage_attn(float* LA, const float* __restrict__ qp, size_t chw, int y0, int y1, int H, int W) {
+    const int S = W + 8, W4 = W >> 2, nrow = y1 - y0 + 2;
+    for (int e = threadIdx.x; e < nrow * 2; e += 256) {          // the pad columns
+        float* p = LA + (e >> 1) * S + ((e & 1) ? 4 + W : 0);
+        *reinterpret_cast<floatx4*>(p) = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int e = threadIdx.x; e < nrow * W4; e += 256) {
+        const int rr = e / W4, x0 = (e - rr * W4) * 4, yy = y0 - 1 + rr;
+        floatx4 a = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H) {
+            const float* row = qp + (size_t)yy * W + x0;
+            const floatx4 q = *reinterpret_cast<const floatx4*>(row), k = *reinterpret_cast<const floatx4*>(row + chw),
+                          v = *reinterpret_cast<const floatx4*>(row + 2 * chw);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = attn_of(q[i], k[i], v[i]);
+        }
+        *reinterpret_cast<floatx4*>(LA + rr * S + 4 + x0) = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void qkv_dw_scaled_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                float* __restrict__ out, int C, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float LA[];
+    const int c = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int rows = (H + WSPLIT - 1) / WSPLIT, y0 = sp * rows, y1 = min(H, y0 + rows);
+    if (y1 <= y0) return;
+    const size_t hw = (size_t)H * W, chw = (size_t)C * hw;
+    stage_attn(LA, qkv + (size_t)b * 3 * chw + (size_t)c * hw, chw, y0, y1, H, W);
+    float wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = w[c * 9 + k];
+    const float b0 = bias ? bias[c] : 0.f, sc = scale[b * C + c];
+    float* op = out + ((size_t)b * C + c) * hw;
+    __syncthreads();
+    const int S = W + 8, W4 = W >> 2, nstrip = (y1 - y0) * W4;
+    for (int sidx = threadIdx.x; sidx < nstrip; sidx += 256) {
+        const int ry = sidx / W4, x0 = (sidx - ry * W4) * 4;
+        float acc[4] = {b0, b0, b0, b0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {                       // tile row ry + dy = image row y - 1 + dy (zero rows outside the image)
+            const float* row = LA + (ry + dy) * S + 4 + x0;
+            const floatx4 m = *reinterpret_cast<const floatx4*>(row);
+            const float v[6] = {row[-1], m[0], m[1], m[2], m[3], row[4]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[q] += wv[dy * 3 + dx] * v[q + dx];
+        }
+        *reinterpret_cast<floatx4*>(op + (size_t)(y0 + ry) * W + x0) = floatx4{acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc};
+    }
+}
+
+// backward of the above in one pass: d attn = s dwconv^T(dy) at the strip, chained through the gate into d q / d k / d v; the
+// (b, row-split, c) weight / bias partials of the scaled stencil (A[t] = sum dy attn_shift_t, G = sum dy: kmu_dwconv3x3_scaled_finish
+// turns them into d weight, d bias, d s) against the attn tile in LDS
+__global__ __launch_bounds__(256) void qkv_dw_scaled_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ qkv,
+                                                                const float* __restrict__ w, const float* __restrict__ scale,
+                                                                float* __restrict__ dqkv, float* __restrict__ dw_part,
+                                                                float* __restrict__ db_part, int C, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float LA[];
+    __shared__ float red[4][10];
+    const int c = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int rows = (H + WSPLIT - 1) / WSPLIT, y0 = sp * rows, y1 = min(H, y0 + rows);
+    const size_t hw = (size_t)H * W, chw = (size_t)C * hw;
+    const float* gp = dy + ((size_t)b * C + c) * hw;
+    const float* qp = qkv + (size_t)b * 3 * chw + (size_t)c * hw;
+    float* dqp = dqkv + (size_t)b * 3 * chw + (size_t)c * hw;
+    if (y1 > y0) stage_attn(LA, qp, chw, y0, y1, H, W);
+    const float sc = scale[b * C + c];
+    float wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = w[c * 9 + 8 - k];
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    __syncthreads();
+    const int S = W + 8, W4 = W >> 2, nstrip = max(0, y1 - y0) * W4;
+    for (int sidx = threadIdx.x; sidx < nstrip; sidx += 256) {
+        const int ry = sidx / W4, y = y0 + ry, x0 = (sidx - ry * W4) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+            const int yy = y + dyy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float* row = gp + (size_t)yy * W;
+            const floatx4 m = *reinterpret_cast<const floatx4*>(row + x0);
+            const float v[6] = {x0 > 0 ? row[x0 - 1] : 0.f, m[0], m[1], m[2], m[3], x0 + 4 < W ? row[x0 + 4] : 0.f};
+            if (dyy == 1) g4[0] = m[0], g4[1] = m[1], g4[2] = m[2], g4[3] = m[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int dxx = 0; dxx < 3; ++dxx) o[q] += wv[dyy * 3 + dxx] * v[q + dxx];
+        }
+        {   // chain rule through attn = sigmoid(q k) v at the strip's 4 pixels (as qkv_gate_bwd_kernel)
+            const size_t e = (size_t)y * W + x0;
+            const floatx4 q = *reinterpret_cast<const floatx4*>(qp + e), k = *reinterpret_cast<const floatx4*>(qp + chw + e),
+                          v = *reinterpret_cast<const floatx4*>(qp + 2 * chw + e);
+            floatx4 dq, dk, dv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float go = o[i] * sc;
+                const float s_ = 1.f / (1.f + __expf(-q[i] * k[i]));
+                const float ds = go * v[i] * s_ * (1.f - s_);
+                dq[i] = ds * k[i];
+                dk[i] = ds * q[i];
+                dv[i] = go * s_;
+            }
+            *reinterpret_cast<floatx4*>(dqp + e) = dq;
+            *reinterpret_cast<floatx4*>(dqp + chw + e) = dk;
+            *reinterpret_cast<floatx4*>(dqp + 2 * chw + e) = dv;
+        }
+        acc[9] += (g4[0] + g4[1]) + (g4[2] + g4[3]);
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+            const float* row = LA + (ry + dyy) * S + 4 + x0;
+            const floatx4 m = *reinterpret_cast<const floatx4*>(row);
+            const float v[6] = {row[-1], m[0], m[1], m[2], m[3], row[4]};
+#pragma unroll
+            for (int dxx = 0; dxx < 3; ++dxx)
+                acc[dyy * 3 + dxx] += (g4[0] * v[dxx] + g4[1] * v[dxx + 1]) + (g4[2] * v[dxx + 2] + g4[3] * v[dxx + 3]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float s_ = kmu::wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s_;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float s_ = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const size_t prow = (size_t)b * WSPLIT + sp;
+        if (threadIdx.x < 9) dw_part[(prow * C + c) * 9 + threadIdx.x] = s_;
+        else db_part[prow * C + c] = s_;
+    }
+}
+
+inline size_t qkv_dw_lds(int H, int W) { return (size_t)((H + WSPLIT - 1) / WSPLIT + 2) * (W + 8) * sizeof(float); }
+
 int launch_stencil(const float* in, const float* w, const float* bias, const float* scale, float* out, int B, int C, int H, int W,
                    int flip, hipStream_t st, const char* what, const float* addend = nullptr) {
     const size_t total = (size_t)B * C * H * ((W + 3) / 4);
@@ -572,6 +723,31 @@ extern "C" int kmu_dwconv3x3_scaled_bwd_all(const float* dy, const float* x, con
     hipLaunchKernelGGL(dwconv3x3_scaled_bwd_all_kernel, dim3(C, B, WSPLIT), dim3(256), 0, (hipStream_t)stream, dy, x, weight, scale, dx,
                        d_weight_partial, d_bias_partial, C, H, W);
     return kmu::launch_status("dwconv3x3_scaled_bwd_all");
+}
+
+// DirectionAttention's gate + stencil as one operator (see qkv_dw_scaled_fwd_kernel); qkv [B,3C,H,W], W % 4 == 0
+extern "C" int kmu_qkv_dw_scaled_supported(int B, int C, int H, int W) {
+    return B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && W % 4 == 0 && qkv_dw_lds(H, W) <= 64 * 1024;
+}
+
+extern "C" int kmu_qkv_dw_scaled_fwd(const float* qkv, const float* weight, const float* bias, const float* scale, float* out, int B, int C,
+                                     int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(qkv && weight && scale && out, "qkv_dw_scaled_fwd: null pointer");
+    KMU_REQUIRE(kmu_qkv_dw_scaled_supported(B, C, H, W), "qkv_dw_scaled_fwd: unsupported dims B=%d C=%d %dx%d (W %% 4 == 0, attn tile <= 64 KB)", B,
+                C, H, W);
+    hipLaunchKernelGGL(qkv_dw_scaled_fwd_kernel, dim3(C, B, WSPLIT), dim3(256), qkv_dw_lds(H, W), (hipStream_t)stream, qkv, weight, bias, scale,
+                       out, C, H, W);
+    return kmu::launch_status("qkv_dw_scaled_fwd");
+}
+
+extern "C" int kmu_qkv_dw_scaled_bwd(const float* dy, const float* qkv, const float* weight, const float* scale, float* dqkv,
+                                     float* d_weight_partial, float* d_bias_partial, int B, int C, int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && qkv && weight && scale && dqkv && d_weight_partial && d_bias_partial, "qkv_dw_scaled_bwd: null pointer");
+    KMU_REQUIRE(kmu_qkv_dw_scaled_supported(B, C, H, W), "qkv_dw_scaled_bwd: unsupported dims B=%d C=%d %dx%d (W %% 4 == 0, attn tile <= 64 KB)", B,
+                C, H, W);
+    hipLaunchKernelGGL(qkv_dw_scaled_bwd_kernel, dim3(C, B, WSPLIT), dim3(256), qkv_dw_lds(H, W), (hipStream_t)stream, dy, qkv, weight, scale,
+                       dqkv, d_weight_partial, d_bias_partial, C, H, W);
+    return kmu::launch_status("qkv_dw_scaled_bwd");
 }
 
 extern "C" int kmu_dwconv3x3_scaled_finish(const float* d_weight_partial, const float* d_bias_partial, const float* scale,

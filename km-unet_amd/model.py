@@ -40,6 +40,7 @@ _SIDE = {}
 _PYR = {}
 
 
+_QKV_DW = _os.environ.get("KMU_QKV_DW", "1") == "1"          # DirectionAttention: sigmoid(q k) v folded into the gated stencil
 _FANOUT = _os.environ.get("KMU_FANOUT", "1") == "1"          # multi-consumer tensors: one gradient fan-in launch (ops.fanout)
 _MEAN_QKV = _os.environ.get("KMU_MEAN_QKV", "1") == "1"      # DirectionAttention: pool + qkv projection as one autograd node
 _PYR_STREAMS = int(_os.environ.get("KMU_PYR_STREAMS", "2"))      # 2: one stream per pyramid, 1: both on one, 0: on the main stream
@@ -155,6 +156,9 @@ class DirectionAttention(nn.Module):
         else:
             gate = gate_mlp(_spatial_mean(x), self.fc[0], self.fc[2], "gelu")
             qkv = conv1x1(x, self.qkv)
+        if _QKV_DW and x.is_cuda and not _TORCH_GLUE and ops.qkv_gate_dw_supported(b, c, qkv.shape[2], qkv.shape[3]):
+            # sigmoid(q*k)*v formed inside the gated stencil, forward and backward: attn is never stored
+            return ops.qkv_gate_dw(qkv, self.conv.weight, self.conv.bias, gate)
         if (qkv.shape[2] * qkv.shape[3]) % 4 == 0 and "qkv_gate" not in _TORCH_GLUE:
             attn = ops.qkv_gate(qkv)                       # sigmoid(q*k)*v, one HIP kernel
         else:

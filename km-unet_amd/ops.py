@@ -1017,6 +1017,55 @@ def dwconv3x3_scaled(x, weight, bias, scale):
     return DwConv3x3ScaledFn.apply(x, weight, bias, scale)
 
 
+class QkvGateDwFn(torch.autograd.Function):
+    """y = scale[b,c] * (depthwise3x3(sigmoid(q*k)*v) + bias) on the packed qkv tensor: DirectionAttention's local gate folded into its
+    stencil (KM_UNetV3_SH.py:258-263); attn is formed on the fly in both directions and never stored."""
+
+    @staticmethod
+    def forward(ctx, qkv, weight, bias, scale):
+        lib = _lib.load()
+        qkv, w = _f32c(qkv, "qkv"), _f32c(weight, "weight")
+        b = None if bias is None else _f32c(bias, "bias")
+        B, C3, H, W = qkv.shape
+        C = C3 // 3
+        sc = _f32c(scale, "scale").view(B, C)
+        y = torch.empty(B, C, H, W, device=qkv.device, dtype=torch.float32)
+        _lib.check(_call(("qkv_dw_scaled_fwd", (B, C, H, W)), lib.kmu_qkv_dw_scaled_fwd, _ptr(qkv), _ptr(w), _ptr(b), _ptr(sc), _ptr(y), B, C,
+                         H, W, _stream()), "kmu_qkv_dw_scaled_fwd")
+        ctx.save_for_backward(qkv, w, b, sc)
+        ctx.sshape = scale.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        qkv, w, b, sc = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        B, C3, H, W = qkv.shape
+        C = C3 // 3
+        st, dev = _stream(), qkv.device
+        P = lib.kmu_dwconv3x3_partials(B)
+        dwp = torch.empty(P, C, 9, device=dev, dtype=torch.float32)
+        dbp = torch.empty(P, C, device=dev, dtype=torch.float32)
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_call(("qkv_dw_scaled_bwd", (B, C, H, W)), lib.kmu_qkv_dw_scaled_bwd, _ptr(dy), _ptr(qkv), _ptr(w), _ptr(sc), _ptr(dqkv),
+                         _ptr(dwp), _ptr(dbp), B, C, H, W, st), "kmu_qkv_dw_scaled_bwd")
+        dw = torch.empty(C, 1, 3, 3, device=dev, dtype=torch.float32)
+        db = torch.empty(C, device=dev, dtype=torch.float32) if b is not None else None
+        ds = torch.empty(B, C, device=dev, dtype=torch.float32)
+        _lib.check(_call(("dwconv3x3_scaled_finish", (B, C)), lib.kmu_dwconv3x3_scaled_finish, _ptr(dwp), _ptr(dbp), _ptr(sc), _ptr(w),
+                         _ptr(b), _ptr(dw), _ptr(db), _ptr(ds), B, C, st), "kmu_dwconv3x3_scaled_finish")
+        return dqkv, dw, db, ds.view(ctx.sshape)
+
+
+def qkv_gate_dw_supported(B, C, H, W):
+    return bool(_lib.load().kmu_qkv_dw_scaled_supported(B, C, H, W))
+
+
+def qkv_gate_dw(qkv, weight, bias, scale):
+    return QkvGateDwFn.apply(qkv, weight, bias, scale)
+
+
 # ------------------------------------------------------------------------------------------ 3-tap axis convolutions
 class Shift3Fn(torch.autograd.Function):
     """[B,C,H,W] -> [B,3C,H,W]: the three copies of x shifted by -1, 0, +1 along `axis` (0 = H, 1 = W), zero padded."""

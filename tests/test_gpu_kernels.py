@@ -795,6 +795,36 @@ def test_spatial_mean_vs_torch_cpu(B, C, H, W):
     _report("spatial_mean %s" % ((B, C, H, W),), y=rel_err(m, x.mean(dim=(2, 3))), dx=rel_err(xd.grad, x.grad))
 
 
+@pytest.mark.parametrize("B,C,H,W,bias", [(2, 16, 32, 32, True), (8, 16, 128, 128, True), (3, 32, 16, 8, False), (2, 64, 8, 12, True),
+                                          (1, 5, 3, 4, True)])
+def test_qkv_gate_dw_vs_torch_cpu(B, C, H, W, bias):
+    """DirectionAttention's sigmoid(q*k)*v folded into its gated depthwise stencil (KM_UNetV3_SH.py:258-263) against torch fp64, and
+    against the two separate HIP operators it replaces."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(3 * C + H)
+    qkv = torch.randn(B, 3 * C, H, W, generator=gen, dtype=torch.float64).requires_grad_(True)
+    w = (0.4 * torch.randn(C, 1, 3, 3, generator=gen, dtype=torch.float64)).requires_grad_(True)
+    bb = torch.randn(C, generator=gen, dtype=torch.float64).requires_grad_(True) if bias else None
+    sc = torch.rand(B, C, generator=gen, dtype=torch.float64).requires_grad_(True)
+    gy = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64)
+    q, k, v = qkv.chunk(3, dim=1)
+    y = torch.nn.functional.conv2d(torch.sigmoid(q * k) * v, w, bb, padding=1, groups=C) * sc.view(B, C, 1, 1)
+    y.backward(gy)
+    dev = lambda t: None if t is None else t.detach().float().to(DEV).requires_grad_(True)
+    qd, wd, bd, sd = dev(qkv), dev(w), dev(bb), dev(sc)
+    yd = ops.qkv_gate_dw(qd, wd, bd, sd)
+    yd.backward(gy.float().to(DEV))
+    errs = dict(y=rel_err(yd, y), dqkv=rel_err(qd.grad, qkv.grad), dw=rel_err(wd.grad, w.grad), ds=rel_err(sd.grad, sc.grad))
+    if bias:
+        errs["db"] = rel_err(bd.grad, bb.grad)
+    _report("qkv_gate_dw %s" % ((B, C, H, W, bias),), **errs)
+    q2, w2, b2, s2 = dev(qkv), dev(w), dev(bb), dev(sc)
+    y2 = ops.dwconv3x3_scaled(ops.qkv_gate(q2), w2, b2, s2) if (H * W) % 4 == 0 else None
+    if y2 is not None:
+        y2.backward(gy.float().to(DEV))
+        assert rel_err(yd, y2) < 1e-6 and rel_err(qd.grad, q2.grad) < 1e-6 and rel_err(wd.grad, w2.grad) < 1e-5
+
+
 @pytest.mark.parametrize("B,C,L", [(2, 16, 1024), (8, 32, 4096), (3, 64, 256), (2, 24, 100)])
 def test_layernorm1d_alias_vs_torch_cpu(B, C, L):
     """LayerNorm1D (vim_utils_init.py:50-59) with a second consumer of its input served by an alias output: the alias' gradient
