@@ -181,6 +181,12 @@ int kmu_deform_conv2d_bwd(const float* x, const float* offset, const float* weig
 int kmu_deform_sample_fwd(const float* x, const float* offset, float* cols, int B, int Cin, int H, int W, kmu_stream_t stream);
 int kmu_deform_sample_bwd(const float* x, const float* offset, const float* dcols, float* dx, float* d_offset, int B, int Cin,
                           int H, int W, kmu_stream_t stream);
+/* the same adjoint without float atomics (round 3): per sample the cell -> (tap, pixel, weight) lists of the bilinear corners are
+ * built once in LDS (integer atomics) and every channel's dx is gathered from them and WRITTEN (dx need not be zeroed).
+ * H*W <= 256 (the bridge's 16x16 level; kmu_deform_sample_bwd_lds_supported) -- larger maps take kmu_deform_sample_bwd. */
+int kmu_deform_sample_bwd_lds_supported(int B, int Cin, int H, int W);
+int kmu_deform_sample_bwd_lds(const float* x, const float* offset, const float* dcols, float* dx, float* d_offset, int B, int Cin, int H,
+                              int W, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Depthwise 3x3 / stride 1 / pad 1 convolution: EfficientViMBlock.dwconv1/dwconv2

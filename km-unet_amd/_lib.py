@@ -48,6 +48,8 @@ SIGNATURES = {
     "kmu_deform_conv2d_bwd": (_I, [_P] * 8 + [_I] * 5 + [_P]),
     "kmu_deform_sample_fwd": (_I, [_P] * 3 + [_I] * 4 + [_P]),
     "kmu_deform_sample_bwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "kmu_deform_sample_bwd_lds_supported": (_I, [_I] * 4),
+    "kmu_deform_sample_bwd_lds": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "kmu_bn_blend_splits": (_I, [_I, _I]),
     "kmu_bn_blend_fwd": (_I, [_P] * 7 + [_c.c_float, _c.c_float, _I, _I] + [_P] * 4 + [_I] * 3 + [_P]),
     "kmu_bn_blend_bwd": (_I, [_P] * 7 + [_I, _I] + [_P] * 6 + [_I] * 3 + [_P]),

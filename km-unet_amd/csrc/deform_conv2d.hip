@@ -240,6 +240,145 @@ __global__ __launch_bounds__(256) void deform_scatter_kernel(const float* __rest
     d_offset[((size_t)b * 18 + 2 * t + 1) * hw + pix] = gx;
 }
 
+// The same adjoint without float atomics (round 3).  The kernel above issues 4.7 M global float atomics onto 131 k cells at the
+// bridge ([8,64,16,16]: 36 addends per cell on average) and took 77 us alone on the main chain.  Measured on the way: LDS float
+// atomics are no way out (ds_add_f32 ~190 cycles per wave instruction here: 92 us for the same scatter into LDS planes), and the
+// d_offset loop -- one thread walking all channels -- was 16 us of it.  What is cheap is that the scatter's DESTINATIONS do not
+// depend on the channel: every workgroup (`chunks` per sample) builds, per sample, the cell -> (item, weight) lists of all 4 * 9 * HW corner
+// contributions once (integer LDS atomics only: a count pass, a prefix sum, a slot pass) and then GATHERS its 2 channels' dx from
+// them: dx[c][cell] = sum over the cell's list of weight * dcols[c][item].  dx is written, not accumulated (no zero fill).  The
+// order inside a list follows the slot atomics, so sums of > 2 addends can differ in the last bit between runs, as before.
+// The same workgroups then compute d_offset (gathers only, 16 lanes per (tap, pixel) item).
+constexpr int SC_CH = 2;
+__global__ __launch_bounds__(256) void deform_scatter_lds_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                                 const float* __restrict__ dcols, float* __restrict__ dx,
+                                                                 float* __restrict__ d_offset, int Cin, int H, int W, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char scl[];
+    const int hw = H * W, b = blockIdx.y, NI = 9 * hw;
+    const float* xb = x + (size_t)b * Cin * hw;
+    {
+        // LDS: start[hw + 1] | cursor[hw] | wgt[4 NI] | itm[4 NI] (u16)
+        int* start = reinterpret_cast<int*>(scl);
+        int* cursor = start + hw + 1;
+        float* wgt = reinterpret_cast<float*>(cursor + hw);
+        unsigned short* itm = reinterpret_cast<unsigned short*>(wgt + 4 * NI);
+        const int c0 = blockIdx.x * SC_CH, nch = min(SC_CH, Cin - c0);
+        for (int e = threadIdx.x; e < 2 * hw + 1; e += 256) start[e] = 0;       // start[] doubles as the count array (shifted by one)
+        // this thread's items (item = threadIdx.x + 256 i): all sample positions are set up first, so their offset loads are in
+        // flight together instead of one dependent round trip per item; the set-ups stay in registers for the slot pass
+        constexpr int MAXI = 9;                                                  // host: 9 * hw <= 256 * MAXI, i.e. hw <= 256
+        Bil sv[MAXI];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int item = threadIdx.x + 256 * i, it = item < NI ? item : 0, t = it / hw, pix = it - t * hw;
+            sv[i] = tap_setup(offset, b, pix / W, pix % W, t, H, W);
+            if (item >= NI) sv[i].ok00 = sv[i].ok01 = sv[i].ok10 = sv[i].ok11 = false;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {                                         // pass 1: how many contributions per cell
+            const Bil& s = sv[i];
+            const int o00 = s.y0 * W + s.x0;
+            if (s.ok00) atomicAdd(start + 1 + o00, 1);
+            if (s.ok01) atomicAdd(start + 1 + o00 + 1, 1);
+            if (s.ok10) atomicAdd(start + 1 + o00 + W, 1);
+            if (s.ok11) atomicAdd(start + 1 + o00 + W + 1, 1);
+        }
+        __syncthreads();
+        {   // inclusive scan of the counts (hw <= 256: one cell per thread; Hillis-Steele through cursor[], cleared afterwards)
+            int v = (int)threadIdx.x < hw ? start[threadIdx.x + 1] : 0;
+            for (int d = 1; d < 256; d <<= 1) {
+                cursor[threadIdx.x] = v;
+                __syncthreads();
+                if ((int)threadIdx.x >= d) v += cursor[threadIdx.x - d];
+                __syncthreads();
+            }
+            if ((int)threadIdx.x < hw) start[threadIdx.x + 1] = v;
+            cursor[threadIdx.x] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {                                         // pass 2: slots
+            const Bil& s = sv[i];
+            const int item = threadIdx.x + 256 * i;
+            const float hy = 1.f - s.ly, hx = 1.f - s.lx;
+            const int o00 = s.y0 * W + s.x0;
+            auto put = [&](int cell, float wv) {
+                const int slot = start[cell] + atomicAdd(cursor + cell, 1);
+                wgt[slot] = wv;
+                itm[slot] = (unsigned short)item;
+            };
+            if (s.ok00) put(o00, hy * hx);
+            if (s.ok01) put(o00 + 1, hy * s.lx);
+            if (s.ok10) put(o00 + W, s.ly * hx);
+            if (s.ok11) put(o00 + W + 1, s.ly * s.lx);
+        }
+        __syncthreads();
+        const float* gc = dcols + ((size_t)b * Cin + c0) * 9 * hw;              // [k][t][pix]: element (k, item) at k * 9 hw + item
+        float* dxb = dx + ((size_t)b * Cin + c0) * hw;
+        // gather: 4 lanes share a cell and take every 4th entry of its list (independent loads in flight), then a 4-lane butterfly
+        for (int cq = threadIdx.x; cq < 4 * hw; cq += 256) {
+            const int cell = cq >> 2, sub = cq & 3;
+            float acc[SC_CH];
+#pragma unroll
+            for (int k = 0; k < SC_CH; ++k) acc[k] = 0.f;
+            const int e1 = start[cell + 1];
+            for (int e = start[cell] + sub; e < e1; e += 4) {
+                const float wv = wgt[e];
+                const float* gp = gc + itm[e];
+#pragma unroll
+                for (int k = 0; k < SC_CH; ++k)
+                    if (k < nch) acc[k] = fmaf(wv, gp[(size_t)k * NI], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < SC_CH; ++k) {
+                acc[k] += __shfl_xor(acc[k], 1, 64);
+                acc[k] += __shfl_xor(acc[k], 2, 64);
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < SC_CH; ++k)
+                    if (k < nch) dxb[(size_t)k * hw + cell] = acc[k];
+            }
+        }
+    }
+    // d_offset: gathers only.  16 lanes share one (tap, pixel) item and split the channels (lane k takes k, k + 16, ...): every lane's
+    // gathers are independent and in flight together, then a 16-lane butterfly sums them.  (One thread per item walking all Cin
+    // channels in rounds of 8 -- the first scatter kernel's loop -- cost 16 us of its 77.)  The sample's 9 HW items are dealt over its
+    // `chunks` workgroups (role B blocks of their own would each reserve the 57 KB list tile for nothing).
+    const int k = threadIdx.x & 15;
+    for (int item = blockIdx.x * 16 + (threadIdx.x >> 4); item < NI; item += 16 * chunks) {
+        const int t = item / hw, pix = item - t * hw;
+        const Bil s = tap_setup(offset, b, pix / W, pix % W, t, H, W);
+        const float hy = 1.f - s.ly, hx = 1.f - s.lx;
+        const int o00 = s.y0 * W + s.x0;
+        const float* gb = dcols + ((size_t)b * Cin * 9 + t) * hw + pix;
+        float gy = 0.f, gx = 0.f;
+        for (int c = k; c < Cin; c += 16) {
+            const float* xc = xb + (size_t)c * hw;
+            const float g = gb[(size_t)c * 9 * hw];
+            const float v0 = s.ok00 ? xc[o00] : 0.f, v1 = s.ok01 ? xc[o00 + 1] : 0.f, v2 = s.ok10 ? xc[o00 + W] : 0.f,
+                        v3 = s.ok11 ? xc[o00 + W + 1] : 0.f;
+            gy += g * (hx * (v2 - v0) + s.lx * (v3 - v1));
+            gx += g * (hy * (v1 - v0) + s.ly * (v3 - v2));
+        }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            gy += __shfl_xor(gy, m, 64);
+            gx += __shfl_xor(gx, m, 64);
+        }
+        if (k == 0) {
+            d_offset[((size_t)b * 18 + 2 * t) * hw + pix] = gy;
+            d_offset[((size_t)b * 18 + 2 * t + 1) * hw + pix] = gx;
+        }
+    }
+}
+
+inline size_t scatter_lds_bytes(int H, int W) {
+    const size_t hw = (size_t)H * W;
+    return (2 * hw + 1) * sizeof(int) + 4 * 9 * hw * (sizeof(float) + sizeof(unsigned short)) + 16;
+}
+
 }  // namespace
 
 extern "C" int kmu_deform_conv2d_fwd(const float* x, const float* offset, const float* weight, const float* bias,
@@ -285,4 +424,19 @@ extern "C" int kmu_deform_sample_bwd(const float* x, const float* offset, const 
     hipLaunchKernelGGL(deform_scatter_kernel, dim3(kmu::cdiv(B * 9 * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, offset, dcols, dx,
                        d_offset, B, Cin, H, W);
     return kmu::launch_status("deform_sample_bwd");
+}
+
+// the list form: dx is WRITTEN (no zero fill needed).  The per-sample cell lists live in LDS: kmu_deform_sample_bwd_lds_supported
+extern "C" int kmu_deform_sample_bwd_lds_supported(int B, int Cin, int H, int W) {
+    return B > 0 && B <= 65535 && Cin > 0 && H > 0 && W > 0 && H * W <= 256 && scatter_lds_bytes(H, W) <= 64 * 1024;
+}
+extern "C" int kmu_deform_sample_bwd_lds(const float* x, const float* offset, const float* dcols, float* dx, float* d_offset, int B, int Cin,
+                                         int H, int W, kmu_stream_t stream) {
+    KMU_REQUIRE(x && offset && dcols && dx && d_offset, "deform_sample_bwd_lds: null pointer");
+    KMU_REQUIRE(kmu_deform_sample_bwd_lds_supported(B, Cin, H, W), "deform_sample_bwd_lds: %dx%d planes do not fit the LDS tile (use kmu_deform_sample_bwd)",
+                H, W);
+    const int chunks = kmu::cdiv(Cin, SC_CH);
+    hipLaunchKernelGGL(deform_scatter_lds_kernel, dim3(chunks, B), dim3(256), scatter_lds_bytes(H, W),
+                       (hipStream_t)stream, x, offset, dcols, dx, d_offset, Cin, H, W, chunks);
+    return kmu::launch_status("deform_sample_bwd_lds");
 }

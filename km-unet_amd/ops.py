@@ -889,7 +889,13 @@ class DeformSampleFn(torch.autograd.Function):
         x, offset = ctx.saved_tensors
         dcols = _f32c(dcols, "dcols")
         B, Cin, H, W = x.shape
-        dx, doff = torch.zeros_like(x), torch.empty_like(offset)
+        doff = torch.empty_like(offset)
+        if lib.kmu_deform_sample_bwd_lds_supported(B, Cin, H, W):     # channel planes accumulated in LDS: no global atomics, no zero fill
+            dx = torch.empty_like(x)
+            _lib.check(_call(("deform_sample_bwd", (B, Cin, H, W)), lib.kmu_deform_sample_bwd_lds, _ptr(x), _ptr(offset), _ptr(dcols), _ptr(dx),
+                             _ptr(doff), B, Cin, H, W, _stream()), "kmu_deform_sample_bwd_lds")
+            return dx, doff
+        dx = torch.zeros_like(x)
         _lib.check(_call(("deform_sample_bwd", (B, Cin, H, W)), lib.kmu_deform_sample_bwd, _ptr(x), _ptr(offset), _ptr(dcols), _ptr(dx),
                          _ptr(doff), B, Cin, H, W, _stream()), "kmu_deform_sample_bwd")
         return dx, doff
