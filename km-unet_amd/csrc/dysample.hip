@@ -234,9 +234,10 @@ __global__ __launch_bounds__(256) void dysample_bwd_tiled_kernel(const float* __
 // (footprint beyond R; needs |0.25 conv_out + init_pos| >= 2 px) is scattered by the tile that owns its source with global atomics,
 // as before: rare, and the only order-dependent sums left in this file.  dx must be zero-initialised (the caller does): the tile's
 // cell sums are ADDED to it, so that far samples from other tiles can land in the same cells.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 constexpr int GT = 8, GR = 2, GS = GT + 2 * GR, GP = GS + 1, GPL = 4 * GS * GP;   // tile, radius, candidate sources per edge, row pitch, plane
 
-__global__ __launch_bounds__(256) void dysample_bwd_gather_kernel(const float* __restrict__ x, const float* __restrict__ conv_out,
+__global__ __launch_bounds__(256, 2) void dysample_bwd_gather_kernel(const float* __restrict__ x, const float* __restrict__ conv_out,
                                                                   const float* __restrict__ init_pos, const float* __restrict__ dy,
                                                                   float* __restrict__ dx, float* __restrict__ d_conv_out, int C, int H,
                                                                   int W, int tilesX) {
@@ -273,22 +274,47 @@ __global__ __launch_bounds__(256) void dysample_bwd_gather_kernel(const float* _
         }
         cx0[idx] = x0, cy0[idx] = y0, cfx[idx] = fx, cfy[idx] = fy, cfl[idx] = fl;
     }
-    for (int e = threadIdx.x; e < cg * 2 * GS * GS; e += 256) {      // two horizontally adjacent outputs (j = 0, 1) per item: 8-byte loads
-        const int c = e / (2 * GS * GS), r = e - c * 2 * GS * GS, i = r / (GS * GS), r2 = r - i * GS * GS, sy = r2 / GS, sx = r2 - sy * GS;
-        const int h = ty0 - GR + sy, w = tx0 - GR + sx;
-        float v0 = 0.f, v1 = 0.f;
-        if (h >= 0 && h < H && w >= 0 && w < W) {
-            const float* p = dyg + ((size_t)c * OH + 2 * h + i) * OW + 2 * w;
-            v0 = p[0], v1 = p[1];
+    // two horizontally adjacent outputs (j = 0, 1) per item: 8-byte loads.  Loads are issued in batches of 6 / 9 before anything is
+    // written to LDS: written as one load -> one LDS store per iteration the compiler waited for every load on its own, 18 + 9
+    // dependent round trips per thread at 2 waves per SIMD (17 k + 13 k of the workgroup's 63 k cycles, measured with clock stamps)
+    constexpr int NDY = cg * 2 * GS * GS, DYB = 6;
+    static_assert(NDY % (256 * DYB) == 0, "dy staging assumes whole batches");
+    for (int base = threadIdx.x; base < NDY; base += 256 * DYB) {
+        floatx2 v[DYB];
+        int dst[DYB];
+#pragma unroll
+        for (int u = 0; u < DYB; ++u) {
+            const int e = base + 256 * u;
+            const int c = e / (2 * GS * GS), r = e - c * 2 * GS * GS, i = r / (GS * GS), r2 = r - i * GS * GS, sy = r2 / GS, sx = r2 - sy * GS;
+            const int h = ty0 - GR + sy, w = tx0 - GR + sx;
+            v[u] = floatx2{0.f, 0.f};
+            if (h >= 0 && h < H && w >= 0 && w < W) v[u] = *reinterpret_cast<const floatx2*>(dyg + ((size_t)c * OH + 2 * h + i) * OW + 2 * w);
+            dst[u] = c * GPL + (2 * i) * GS * GP + sy * GP + sx;
         }
-        gos[c * GPL + (2 * i) * GS * GP + sy * GP + sx] = v0;
-        gos[c * GPL + (2 * i + 1) * GS * GP + sy * GP + sx] = v1;
+#pragma unroll
+        for (int u = 0; u < DYB; ++u) {
+            gos[dst[u]] = v[u][0];
+            gos[dst[u] + GS * GP] = v[u][1];
+        }
     }
     if (myrad) atomicMax(rad, myrad);
-    for (int e = threadIdx.x; e < cg * GS * GS; e += 256) {
-        const int c = e / (GS * GS), r = e - c * GS * GS, sy = r / GS, sx = r - sy * GS;
-        const int h = ty0 - GR + sy, w = tx0 - GR + sx;
-        xw[c * GS * GP + sy * GP + sx] = (h >= 0 && h < H && w >= 0 && w < W) ? x[((size_t)b * C + (size_t)g * cg + c) * hw + (size_t)h * W + w] : 0.f;
+    {
+        constexpr int NXW = cg * GS * GS, XB = NXW / 256;
+        static_assert(NXW % 256 == 0, "x window staging assumes whole passes");
+        float v[XB];
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int c = e / (GS * GS), r = e - c * GS * GS, sy = r / GS, sx = r - sy * GS;
+            const int h = ty0 - GR + sy, w = tx0 - GR + sx;
+            v[u] = (h >= 0 && h < H && w >= 0 && w < W) ? x[((size_t)b * C + (size_t)g * cg + c) * hw + (size_t)h * W + w] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int c = e / (GS * GS), r = e - c * GS * GS, sy = r / GS, sx = r - sy * GS;
+            xw[c * GS * GP + sy * GP + sx] = v[u];
+        }
     }
     __syncthreads();
     // ---- phase 1: offset gradient of the tile's own 16 x 16 outputs (16 channel lanes per output: a DPP row sum), far samples scattered
@@ -346,21 +372,30 @@ __global__ __launch_bounds__(256) void dysample_bwd_gather_kernel(const float* _
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const float* g4 = gos + (size_t)(4 * cq) * GPL;
         const int rr = *rad;             // candidates beyond the largest near footprint of this tile cannot contribute: usually 1, not GR
-        for (int dh = GR - rr; dh <= GR + rr; ++dh)
-            for (int dw = GR - rr; dw <= GR + rr; ++dw)
+        auto cand = [&](int dh, int dw) {
 #pragma unroll
-                for (int ij = 0; ij < 4; ++ij) {
-                    const int idx = ij * GS * GP + (wy + dh) * GP + wx + dw;       // source (yy + dh - R, xx + dw - R)
-                    const int x0 = cx0[idx], y0 = cy0[idx];
-                    const float fx = cfx[idx], fy = cfy[idx];
-                    const bool use = x0 >= 0 && !(cfl[idx] & 4);
-                    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-                    const float wxp = (x0 == xx ? 1.f - fx : 0.f) + (x1 == xx ? fx : 0.f);
-                    const float wyp = (y0 == yy ? 1.f - fy : 0.f) + (y1 == yy ? fy : 0.f);
-                    const float wgt = use ? wxp * wyp : 0.f;
+            for (int ij = 0; ij < 4; ++ij) {
+                const int idx = ij * GS * GP + (wy + dh) * GP + wx + dw;       // source (yy + dh - R, xx + dw - R)
+                const int x0 = cx0[idx], y0 = cy0[idx];
+                const float fx = cfx[idx], fy = cfy[idx];
+                const bool use = x0 >= 0 && !(cfl[idx] & 4);
+                const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+                const float wxp = (x0 == xx ? 1.f - fx : 0.f) + (x1 == xx ? fx : 0.f);
+                const float wyp = (y0 == yy ? 1.f - fy : 0.f) + (y1 == yy ? fy : 0.f);
+                const float wgt = use ? wxp * wyp : 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[k] += g4[k * GPL + idx] * wgt;
-                }
+                for (int k = 0; k < 4; ++k) acc[k] += g4[k * GPL + idx] * wgt;
+            }
+        };
+        if (rr <= 1) {                   // the model's case (offsets of a fraction of a pixel): one row of 3 x 4 candidates unrolled at a
+#pragma unroll 1                         // time, so their LDS reads are in flight together (same candidates, same order as the general
+            for (int dh = GR - 1; dh <= GR + 1; ++dh)      // loop; all 36 at once needs 291 VGPRs = one wave per SIMD: 163 us instead of 120)
+#pragma unroll
+                for (int dw = GR - 1; dw <= GR + 1; ++dw) cand(dh, dw);
+        } else {
+            for (int dh = GR - rr; dh <= GR + rr; ++dh)
+                for (int dw = GR - rr; dw <= GR + rr; ++dw) cand(dh, dw);
+        }
         if (yy < H && xx < W) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) atomicAdd(dx + ((size_t)b * C + (size_t)g * cg + 4 * cq + k) * hw + (size_t)yy * W + xx, acc[k]);
