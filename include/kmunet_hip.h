@@ -382,6 +382,9 @@ int kmu_gate_mlp_bwd(const float* p, const float* w1, const float* w2, const flo
  * arrays src[k] = [rows[k]][cols[k]] -> dst[k] = [cols[k]] in one launch.  srcs/dsts/rows/cols are HOST arrays of
  * length n holding device pointers / sizes.  (No reference counterpart: autograd's SumBackward does this.)
  * ------------------------------------------------------------------------------------ */
+/* dsts[i][c] = sum over (b, pixel) of srcs[i][b][c][pixel], srcs[i] = [B[i], C[i], HW[i]] contiguous, up to 32 tensors per launch: the
+ * bias gradients of the plain nn.Conv2d layers (KM_UNetV3_SH.py:300-306, :375, :430-446; DAGEM_md.py:43) in the backward's tail. */
+int kmu_bias_sum_multi(int n, const float* const* srcs, float* const* dsts, const int* B, const int* C, const int* HW, kmu_stream_t stream);
 /* out = ((a + b) + c) + d over numel floats (c, d may be NULL): the gradient fan-in of a tensor with up to four consumers in one
  * launch -- EnhancedViMBlock's x feeds the three direction branches and the residual (KM_UNetV3_SH.py:141-146); e1 / e2 feed the
  * next encoder stage and both MultiScaleFusion pyramids (:487-509).  Autograd itself accumulates pairwise, one launch per extra use. */

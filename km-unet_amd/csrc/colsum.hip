@@ -95,7 +95,62 @@ __global__ __launch_bounds__(256) void add_n_kernel(const float* __restrict__ a,
         }
 }
 
+// bias gradients of the plain convolutions: out[c] = sum over (b, pixel) of dy[b][c][pixel] for up to 32 tensors in one launch (ATen
+// ran one reduce_kernel per convolution in the backward's tail: 27 launches, 0.28 ms of kernel time per step).  One workgroup per
+// (tensor, channel), fixed summation order.
+constexpr int BS_MAX = 32;
+struct BiasSumArgs {
+    const float* src[BS_MAX];
+    float* dst[BS_MAX];
+    int B[BS_MAX], C[BS_MAX], HW[BS_MAX], blk0[BS_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void bias_sum_multi_kernel(BiasSumArgs a) {
+    __shared__ float red[4];
+    int k = 0;
+    while (k + 1 < a.n && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
+    const int c = blockIdx.x - a.blk0[k], B = a.B[k], C = a.C[k], HW = a.HW[k];
+    const float* __restrict__ s = a.src[k];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if ((HW & 3) == 0 && (((size_t)s) & 15) == 0) {
+        const int q = HW >> 2;
+        for (int b = 0; b < B; ++b) {
+            const kmu::floatx4* p = reinterpret_cast<const kmu::floatx4*>(s + ((size_t)b * C + c) * HW);
+            for (int i = threadIdx.x; i < q; i += 256) {
+                const kmu::floatx4 v = p[i];
+                s0 += v[0], s1 += v[1], s2 += v[2], s3 += v[3];
+            }
+        }
+    } else {
+        for (int b = 0; b < B; ++b) {
+            const float* p = s + ((size_t)b * C + c) * HW;
+            for (int i = threadIdx.x; i < HW; i += 256) s0 += p[i];
+        }
+    }
+    float v = kmu::wave_sum((s0 + s1) + (s2 + s3));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) a.dst[k][c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
+
+extern "C" int kmu_bias_sum_multi(int n, const float* const* srcs, float* const* dsts, const int* B, const int* C, const int* HW,
+                                  kmu_stream_t stream) {
+    KMU_REQUIRE(n > 0 && n <= BS_MAX && srcs && dsts && B && C && HW, "bias_sum_multi: %d tensors (1..%d supported)", n, BS_MAX);
+    BiasSumArgs a;
+    a.n = n;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        KMU_REQUIRE(srcs[k] && dsts[k] && B[k] > 0 && C[k] > 0 && HW[k] > 0, "bias_sum_multi: tensor %d is empty or null", k);
+        a.src[k] = srcs[k], a.dst[k] = dsts[k], a.B[k] = B[k], a.C[k] = C[k], a.HW[k] = HW[k];
+        a.blk0[k] = blocks;
+        blocks += C[k];
+    }
+    a.blk0[n] = blocks;
+    hipLaunchKernelGGL(bias_sum_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return kmu::launch_status("bias_sum_multi");
+}
 
 extern "C" int kmu_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long long numel, kmu_stream_t stream) {
     KMU_REQUIRE(a && b && out && numel > 0 && (c || !d), "add_n: needs a, b, out (c before d)");

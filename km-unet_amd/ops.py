@@ -150,7 +150,7 @@ def flush_wgrad_jobs(final=True):
                 side.wait_event(ev)
             _WG_BUSY.add(side)
         global _WG_BATCH
-        batch = _WG_BATCH = {"colsum": [], "pwred": [], "pw": []} if final else None
+        batch = _WG_BATCH = {"colsum": [], "pwred": [], "pw": [], "bsum": []} if final else None
         try:
             for i, (_, job) in enumerate(_WG_JOBS):
                 with torch.cuda.stream(sides[i % len(sides)]):
@@ -290,10 +290,33 @@ def _issue_pw_partials(batch, lanes):
             batch["pwred"].extend((c[2], c[3], c[4], B, ci, co, P) for c in ch)
 
 
+def bias_sum(dy, db):
+    """db[c] = sum of dy[b, c, ...] over batch and pixels (a convolution's bias gradient).  Inside the final weight-gradient flush the
+    request is only registered: all of them go out as one kmu_bias_sum_multi launch on the joining stream."""
+    if _WG_BATCH is not None and "bsum" in _WG_BATCH:
+        _WG_BATCH["bsum"].append((dy, db))
+        return
+    _bias_sum_launch([(dy, db)])
+
+
+def _bias_sum_launch(pairs):
+    import ctypes
+    lib, st = _lib.load(), _stream()
+    for i in range(0, len(pairs), 32):
+        ch = pairs[i:i + 32]
+        n = len(ch)
+        vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+        _lib.check(_call(("bias_sum_multi", (n,)), lib.kmu_bias_sum_multi, n, vp(*[d.data_ptr() for d, _ in ch]), vp(*[o.data_ptr() for _, o in ch]),
+                         ip(*[d.shape[0] for d, _ in ch]), ip(*[d.shape[1] for d, _ in ch]),
+                         ip(*[d.numel() // (d.shape[0] * d.shape[1]) for d, _ in ch]), st), "kmu_bias_sum_multi")
+
+
 def _issue_batched(batch):
     import ctypes
     lib = _lib.load()
     st = _stream()
+    if batch.get("bsum"):
+        _bias_sum_launch(batch["bsum"])
     red = batch["pwred"]
     for i in range(0, len(red), 32):
         ch = red[i:i + 32]
@@ -605,7 +628,7 @@ class ConvKxKFn(torch.autograd.Function):
                 _lib.check(_call(("conv%dx%d_bwd_weight_x3" % (K, K), (B, Cin, Cout, H, W)), lib.kmu_conv2d_bwd_weight_x3, _ptr(x), _ptr(dy),
                                  _ptr(dw), _ptr(ws), nbytes, B, Cin, Cout, H, W, K, _stream()), "kmu_conv2d_bwd_weight_x3")
             if db is not None:
-                torch.sum(dy, dim=(0, 2, 3), out=db)
+                bias_sum(dy, db)
         if dw is not None or db is not None:
             _wgrad(job, ctx.defer_wgrad, heavy=True)
         return dx, dw, db

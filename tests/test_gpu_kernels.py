@@ -1134,6 +1134,18 @@ def test_fanout_sums_gradients_like_autograd(n, shape):
     assert ops.fanout(x, 3)[0] is x          # no gradient wanted: plain aliases
 
 
+def test_bias_sum_multi_vs_torch():
+    """kmu_bias_sum_multi: the bias gradients of several convolutions (ragged shapes, HW % 4 != 0 included) in one launch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(8, 16, 128, 128), (8, 5, 128, 128), (2, 18, 16, 16), (3, 7, 5, 9), (1, 1, 1, 1)]
+    pairs = [(torch.randn(*s, generator=g).to(DEV), torch.empty(s[1], device=DEV)) for s in shapes]
+    ops._bias_sum_launch(pairs)
+    for dy, db in pairs:
+        ref = dy.double().sum(dim=(0, 2, 3))
+        assert rel_err(db, ref) < 1e-5, tuple(dy.shape)
+
+
 def test_copy_multi_matches_foreach_copy():
     """kmu_copy_multi (gradients -> flat bucket): 700 tensors of ragged sizes at unaligned offsets of one flat buffer, bit-exact."""
     ops = _ops()
