@@ -49,11 +49,11 @@ RIDGE = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # FLOP/B at which f
 
 
 def pmc_traffic(name, shape):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03b_pmc_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03c_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), measured at the bench shape only; None for
     kernels / shapes without a PMC pass."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r03b_pmc_traffic.json")))["kernels"]
+        table = json.load(open(os.path.join(ROOT, "profiles", "r03c_pmc_traffic.json")))["kernels"]
     except Exception:
         return None
     key = {("hsmssd_bwd_passB", (8, 16, 128)): "hsm_bwd_passB<16>", ("hsmssd_bwd_passA_x3", (8, 16, 128)): "hsm_bwd_passA_x3<16>",
