@@ -84,9 +84,12 @@ def _ptr(t):
 WGRAD_OVERLAP = False
 WGRAD_BATCH = int(os.environ.get("KMU_WGRAD_BATCH", "4096"))
 WGRAD_STREAMS = int(os.environ.get("KMU_WGRAD_STREAMS", "4"))      # 3 vs 4 vs 5: within the box-to-box noise (+-0.07 ms)
-# dense-conv weight gradients started where autograd reaches them instead of in the tail: measured neutral (10.17 / 10.22 vs
-# 10.18 / 10.09 ms/step, interleaved on one box) -- the backward chain already keeps the device busy; off by default
+# dense-conv weight gradients started where autograd reaches them instead of in the tail: all 16 of them neutral (10.17 / 10.22 vs
+# 10.18 / 10.09 ms/step), only the decoder's first 4 (KMU_WGRAD_EARLY_N) WORSE (9.61 / 9.58 / 9.61 / 9.62 vs 9.43 / 9.53 / 9.44 / 9.45,
+# four interleaved pairs): a 100 us kernel beside the activation-gradient chain slows the chain's own kernels by more than the tail
+# gets shorter; off by default
 WGRAD_EARLY = os.environ.get("KMU_WGRAD_EARLY", "0") == "1"
+WGRAD_EARLY_N = int(os.environ.get("KMU_WGRAD_EARLY_N", "1000"))    # only the first N dense-conv jobs of a backward pass (the decoder's) go early
 _WG_EARLY = {}
 _WG_EARLY_KEEP = []
 WGRAD_GROUP = os.environ.get("KMU_WGRAD_GROUP", "1") == "1"     # identical pointwise-conv weight gradients share a launch
@@ -112,7 +115,7 @@ def _wgrad(job, defer=True, heavy=False):
     if not (WGRAD_OVERLAP and defer):
         job()
         return
-    if heavy and WGRAD_EARLY:
+    if heavy and WGRAD_EARLY and len(_WG_EARLY_KEEP) < WGRAD_EARLY_N:
         # the dense KxK / KAN weight gradients (16 jobs of 30-110 us, ~1 ms per step) are long enough to pay for a cross-stream
         # edge each: they start at once on a stream of their own, beside the activation-gradient chain, instead of in the tail.
         # The closure (holding x and dy) is kept until the final join: the producers' allocator must not recycle their blocks
