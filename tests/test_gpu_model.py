@@ -269,9 +269,10 @@ def test_branch_streams_match_serial(monkeypatch):
         e = (res[True][1][k] - v).abs().max().item() / max(v.abs().max().item(), 1e-4 * gmax)
         worst = max(worst, (k, e), key=lambda t: t[1])
     print("  [branch streams] worst parameter-gradient difference %.2e (%s)" % (worst[1], worst[0]))
-    # 1e-3: a missing stream dependency shows up as O(1); what remains is the atomic-order noise of DySample / deformable-conv
-    # backward amplified by cancellation in scalar parameters (HSMSSD.D: 1.9e-4 observed)
-    assert worst[1] < 1e-3
+    # 1e-4 (round 2: 1e-3): a missing stream dependency shows up as O(1).  Since round 3 DySample's backward sums its candidates in a
+    # fixed order and the deformable-conv adjoint gathers from per-sample lists, so only the list order / far-sample atomics are left
+    # of the run-to-run noise, amplified by cancellation in scalar parameters (HSMSSD.D: 2.8e-5 observed; 1.9e-4 in round 2)
+    assert worst[1] < 1e-4
 
 
 def test_wgrad_side_streams_match_serial(monkeypatch):
