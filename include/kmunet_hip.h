@@ -385,6 +385,9 @@ int kmu_gate_mlp_bwd(const float* p, const float* w1, const float* w2, const flo
 /* dsts[i][c] = sum over (b, pixel) of srcs[i][b][c][pixel], srcs[i] = [B[i], C[i], HW[i]] contiguous, up to 32 tensors per launch: the
  * bias gradients of the plain nn.Conv2d layers (KM_UNetV3_SH.py:300-306, :375, :430-446; DAGEM_md.py:43) in the backward's tail. */
 int kmu_bias_sum_multi(int n, const float* const* srcs, float* const* dsts, const int* B, const int* C, const int* HW, kmu_stream_t stream);
+/* out = y > 0 ? dy : 0 over numel floats: the gradient through the ReLU behind StableHybridKANConv's residual add
+ * (KM_UNetV3_SH.py:91-94), one launch (ATen: gt + mul). */
+int kmu_relu_mask(const float* dy, const float* y, float* out, long long numel, kmu_stream_t stream);
 /* out = ((a + b) + c) + d over numel floats (c, d may be NULL): the gradient fan-in of a tensor with up to four consumers in one
  * launch -- EnhancedViMBlock's x feeds the three direction branches and the residual (KM_UNetV3_SH.py:141-146); e1 / e2 feed the
  * next encoder stage and both MultiScaleFusion pyramids (:487-509).  Autograd itself accumulates pairwise, one launch per extra use. */

@@ -88,6 +88,7 @@ SIGNATURES = {
     "kmu_colsum_multi": (_I, [_I, _P, _P, _P, _P, _P]),
     "kmu_copy_multi": (_I, [_I, _P, _P, _P, _P]),
     "kmu_add_n": (_I, [_P] * 5 + [_c.c_longlong, _P]),
+    "kmu_relu_mask": (_I, [_P] * 3 + [_c.c_longlong, _P]),
     "kmu_bias_sum_multi": (_I, [_I] + [_P] * 5 + [_P]),
     "kmu_group_norm_splits": (_I, [_I]),
     "kmu_group_norm_fwd": (_I, [_P] * 6 + [_I] * 4 + [_c.c_float, _P]),

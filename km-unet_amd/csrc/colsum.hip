@@ -133,7 +133,30 @@ __global__ __launch_bounds__(256) void bias_sum_multi_kernel(BiasSumArgs a) {
     if (threadIdx.x == 0) a.dst[k][c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// out = y > 0 ? dy : 0 -- the ReLU behind StableHybridKANConv's residual add (KM_UNetV3_SH.py:91-94) in the backward: ATen ran `gt` + `mul`
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+                                                        size_t n4, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const kmu::floatx4 g = reinterpret_cast<const kmu::floatx4*>(dy)[i], v = reinterpret_cast<const kmu::floatx4*>(y)[i];
+        reinterpret_cast<kmu::floatx4*>(out)[i] = kmu::floatx4{v[0] > 0.f ? g[0] : 0.f, v[1] > 0.f ? g[1] : 0.f, v[2] > 0.f ? g[2] : 0.f,
+                                                              v[3] > 0.f ? g[3] : 0.f};
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = 4 * n4 + threadIdx.x; i < n; i += 256) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
 }  // namespace
+
+extern "C" int kmu_relu_mask(const float* dy, const float* y, float* out, long long numel, kmu_stream_t stream) {
+    KMU_REQUIRE(dy && y && out && numel > 0, "relu_mask: bad arguments");
+    const bool vec = ((((size_t)dy | (size_t)y | (size_t)out) & 15) == 0);
+    const size_t n4 = vec ? (size_t)numel / 4 : 0;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, n4, (size_t)numel);
+    return kmu::launch_status("relu_mask");
+}
 
 extern "C" int kmu_bias_sum_multi(int n, const float* const* srcs, float* const* dsts, const int* B, const int* C, const int* HW,
                                   kmu_stream_t stream) {

@@ -531,7 +531,10 @@ class KanConv2dFn(torch.autograd.Function):
         x, knots, spline_w, scaler, wp_b, y, base_w = ctx.saved_tensors
         dy = _f32c(dy, "dy")
         if ctx.relu:
-            dy = dy * (y > 0)
+            masked = torch.empty_like(dy)
+            _lib.check(_call(("relu_mask", (dy.numel(),)), lib.kmu_relu_mask, _ptr(dy), _ptr(y), _ptr(masked), dy.numel(), _stream()),
+                       "kmu_relu_mask")
+            dy = masked
         B, Cin, H, W = x.shape
         Cout = dy.shape[1]
         st = _stream()
