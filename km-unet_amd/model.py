@@ -24,6 +24,7 @@ import os as _os
 # (34.1 vs 30.6 ms/step); inside the captured hipGraph the branches become parallel graph branches and their small kernels
 # overlap: 17.16 vs 17.91 ms/step (round 2, B=8).  On by default; KMU_BRANCH_STREAMS=0 serialises them again.
 _BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") == "1"
+_BRANCH_MIN_C = int(_os.environ.get("KMU_BRANCH_MIN_C", "0"))      # fork only levels with at least this many channels
 # KMU_GROUPED_BRANCHES=1: the three direction branches stacked along the channel axis, one launch per layer (grouped.py), instead of
 # three passes on side streams.  Measured on MI355X (B = 8, round 2): 1380 instead of 1837 launches and 14.4 instead of 17.7 ms of
 # serialised kernel time per step -- but 13.5 ms/step against 12.9 for the forked branches (grouped only at C >= 32: 13.0, C >= 64:
@@ -236,7 +237,7 @@ class EnhancedViMBlock(nn.Module):
         64x64 / 32x32 levels are far too small to fill 256 CUs one at a time.  xw / xc: aliases of x for the width / channel
         branch (ops.fanout: one gradient fan-in launch instead of pairwise adds)."""
         xw, xc = (x if xw is None else xw), (x if xc is None else xc)
-        if not (x.is_cuda and _BRANCH_STREAMS):
+        if not (x.is_cuda and _BRANCH_STREAMS and x.shape[1] >= _BRANCH_MIN_C):
             return [self.height_block(x), self.width_block(xw), self.channel_block(xc)]
         cur = torch.cuda.current_stream()
         side = _side_streams(x.device)
