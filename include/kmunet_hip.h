@@ -608,6 +608,27 @@ size_t kmu_hsmssd_pack_elems(int C, int groups);      /* bf16 elements */
 int kmu_hsmssd_pack_x3(const float* w_bcdt, const float* w_dw, void* wpk, int C, int groups, kmu_stream_t stream);
 int kmu_hsm_pack_job(void* host_table, int index, const float* w_bcdt, const float* w_dw, void* wpk, int C, int groups);
 int kmu_hsm_pack_multi(const void* device_table, int njobs, kmu_stream_t stream);
+/* ------------------------------------------------------------------------------------
+ * K2 forward, round-4 form: LayerNorm1D (vim_utils_init.py:50-59) + HSMSSD.forward (efficient_vim_init.py:33-61) in TWO launches
+ * (csrc/hsmssd_v2.inc).
+ *   stage 0  pass 1: LayerNorm on load, B / dt rows (1x1 projection on the bf16 matrix core, depthwise 3x3 in registers), online
+ *            softmax partials per 4H x 16 token tile; the workgroup that draws the LAST atomic ticket of a sample combines the
+ *            sample's tiles in tile order, applies hz_proj / SiLU gate / out_proj (:52-55), writes `state` (layout of
+ *            kmu_hsmssd_fwd: [M | S | hpre | hz | h2], read by kmu_hsmssd_bwd*), h, and the per-sample dense 3x3 weights
+ *            M_b = h2 . Wc of stage 1 into ws.  No workgroup waits for another one.
+ *   stage 1  pass 2: y = conv3x3(LayerNorm(x); M_b)  (== h2 . Cm, :57-59); optional outputs xn [B,C,L] (the normalised x: the
+ *            `x` operand of kmu_hsmssd_bwd*) and rstd_mean [B,L,2] (kmu_layernorm1d_bwd*).
+ * ln_weight / ln_bias [groups, C] (both NULL: no LayerNorm, x is the mixer input itself, xn / rstd_mean must be NULL).
+ * wpk: kmu_hsmssd_pack_x3 / kmu_hsm_pack_multi output (kmu_hsmssd_pack_elems elements).  groups as kmu_hsmssd_*_g.
+ * tickets: B zero-initialised 32-bit words in device memory that no other in-flight launch uses; the kernel leaves them zero.
+ * ------------------------------------------------------------------------------------ */
+size_t kmu_mixer_fwd_ws_bytes(int B, int C, int N, int Hs);
+int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const float* ln_bias, float eps, const float* w_dw, const float* w_hz,
+                        const float* w_out, const float* D, const void* wpk, float* y, float* h, float* state, float* xn,
+                        float* rstd_mean, void* ws, size_t ws_bytes, unsigned int* tickets, int B, int C, int N, int Hs, int stage,
+                        int groups, kmu_stream_t stream);
+void kmu_mixer_debug_rows(int rows); /* tools only: force pass 1's rows per lane group (1 / 2 / 4; 0 = automatic) */
+
 /* kmu_hsmssd_{fwd,bwd}_stage_x3_g with the pack handed in (wpk NULL: pack inside stage 0 as before) */
 int kmu_hsmssd_fwd_stage_x3_pk(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
                                const float* D, float* y, float* h, float* state, void* ws, size_t ws_bytes, int B, int C, int N, int Hs,

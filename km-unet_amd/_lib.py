@@ -139,6 +139,9 @@ SIGNATURES = {
     "kmu_hsm_pack_multi": (_I, [_P, _I, _P]),
     "kmu_hsmssd_fwd_stage_x3_pk": (_I, [_P] * 10 + [_Z] + [_I] * 6 + [_P, _P]),
     "kmu_hsmssd_bwd_stage_x3_pk": (_I, [_P] * 16 + [_Z] + [_I] * 6 + [_P, _P]),
+    "kmu_mixer_fwd_ws_bytes": (_Z, [_I] * 4),
+    "kmu_mixer_fwd_stage": (_I, [_P] * 3 + [_c.c_float] + [_P] * 11 + [_Z, _P] + [_I] * 6 + [_P]),
+    "kmu_mixer_debug_rows": (None, [_I]),
     "kmu_gate_mlp_fwd_g": (_I, [_P] * 7 + [_I] * 7 + [_P]),
     "kmu_gate_mlp_bwd_g": (_I, [_P] * 11 + [_I] * 7 + [_P]),
     "kmu_mix3_fwd_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),

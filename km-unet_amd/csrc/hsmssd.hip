@@ -694,6 +694,7 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
 }
 
 #include "hsmssd_x3.inc"
+#include "hsmssd_v2.inc"
 #include "hsmssd_bwd.inc"
 
 // backward on the matrix core: ws = [partA | dhpre | delta | composite weights (fragment order) | transposed composite weights]
@@ -1023,3 +1024,36 @@ extern "C" int kmu_hsmssd_bwd_stage_x3_pk(const float* x, const float* dy, const
     return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
                              d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups, wpk);
 }
+
+// ---- round 4: LayerNorm1D + HSMSSD forward in two launches (csrc/hsmssd_v2.inc) ---------------------------------------------
+extern "C" size_t kmu_mixer_fwd_ws_bytes(int B, int C, int N, int Hs) {
+    (void)N;
+    return v2_ws_bytes(B, C, Hs);
+}
+
+extern "C" int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const float* ln_bias, float eps, const float* w_dw,
+                                   const float* w_hz, const float* w_out, const float* D, const void* wpk, float* y, float* h, float* state,
+                                   float* xn, float* rstd_mean, void* ws, size_t ws_bytes, unsigned int* tickets, int B, int C, int N,
+                                   int Hs, int stage, int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(x && w_dw && w_hz && w_out && D && wpk && y && h && state && ws && tickets, "mixer_fwd: null pointer");
+    KMU_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "mixer_fwd: LayerNorm weight and bias come together (both NULL: x is used as it is)");
+    KMU_REQUIRE(!ln_weight || ((xn == nullptr) == (rstd_mean == nullptr)), "mixer_fwd: xn and rstd_mean come together");
+    KMU_REQUIRE(ln_weight || (!xn && !rstd_mean), "mixer_fwd: xn / rstd_mean are outputs of the LayerNorm prologue only");
+    KMU_REQUIRE(N == NS, "mixer_fwd: state_dim=%d unsupported (kernels are built for 64)", N);
+    KMU_REQUIRE(C == 16 || C == 32 || C == 64, "mixer_fwd: C=%d unsupported (16/32/64)", C);
+    KMU_REQUIRE(B > 0 && B <= 65535 && Hs > 0 && groups >= 1 && B % groups == 0, "mixer_fwd: bad dims");
+    KMU_REQUIRE(stage == 0 || stage == 1, "mixer_fwd: stage must be 0 (pass 1 + gate) or 1 (pass 2)");
+    KMU_REQUIRE(ws_bytes >= v2_ws_bytes(B, C, Hs), "mixer_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16)
+        return v2_fwd_impl<16>(x, ln_weight, ln_bias, eps, wpk, w_dw, w_hz, w_out, D, y, h, state, xn, rstd_mean, (float*)ws, tickets, B, Hs,
+                               1 << stage, groups, st);
+    if (C == 32)
+        return v2_fwd_impl<32>(x, ln_weight, ln_bias, eps, wpk, w_dw, w_hz, w_out, D, y, h, state, xn, rstd_mean, (float*)ws, tickets, B, Hs,
+                               1 << stage, groups, st);
+    return v2_fwd_impl<64>(x, ln_weight, ln_bias, eps, wpk, w_dw, w_hz, w_out, D, y, h, state, xn, rstd_mean, (float*)ws, tickets, B, Hs,
+                           1 << stage, groups, st);
+}
+
+// tools only: force the tile height of pass 1 (rows per lane group: 1, 2 or 4; 0 = choose by grid size)
+extern "C" void kmu_mixer_debug_rows(int rows) { g_v2_rows_override = (rows == 1 || rows == 2 || rows == 4) ? rows : 0; }

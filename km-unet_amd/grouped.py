@@ -377,7 +377,7 @@ def supported(blocks, x):
     C, HW = x.shape[1], x.shape[2] * x.shape[3]
     e = blocks[0].vit_mamba
     hid = e.ffn.fc1.conv.out_channels
-    return (x.is_cuda and ops.K2_MATH == "bf16x3" and C in (16, 32, 64) and HW % 64 == 0 and int(round(HW ** 0.5)) ** 2 == HW and
+    return (x.is_cuda and ops.K2_MATH != "f32" and C in (16, 32, 64) and HW % 64 == 0 and int(round(HW ** 0.5)) ** 2 == HW and
             ops.pwconv_supported(C, hid, HW) and ops.pwconv_supported(C, 3 * C, HW) and
             all(b.vit_mamba.ffn.fc1.conv.out_channels == hid and b.vit_mamba.mixer.state_dim == 64 for b in blocks))
 

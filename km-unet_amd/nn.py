@@ -16,7 +16,6 @@ import os as _os
 
 # Debug only (tests/tools): comma list of fused glue ops to route back through stock PyTorch, e.g.
 # KMU_GLUE_TORCH=bn_blend,dwconv,conv1x1,qkv_gate -- used to bisect numerics; never set in production.
-_LN_ALIAS = _os.environ.get("KMU_LN_ALIAS", "1") == "1"      # EfficientViMBlock: blend partner = alias made by the LayerNorm node
 _TORCH_GLUE = set(filter(None, _os.environ.get("KMU_GLUE_TORCH", "").split(",")))
 
 
@@ -285,10 +284,11 @@ class EfficientViMBlock(nn.Module):
                 and ops.pwconv_supported(c, self.ffn.fc1.conv.out_channels, hh * ww):
             # each stage as ONE autograd node: its backward folds the blend partner's gradient into the branch's last kernel
             x = ops.dw_bn_blend(x, self.dwconv1.conv, self.dwconv1.norm, a0)
-            # x feeds the norm AND the blend: the blend takes an alias whose gradient the LayerNorm backward kernel adds in
-            xn, xa = ops.layernorm1d_alias(x.flatten(2), self.norm.weight, self.norm.bias, self.norm.eps) if _LN_ALIAS else \
-                (self.norm(x.flatten(2)), x)
-            y, _ = self.mixer(xn)
+            # LayerNorm1D + HSMSSD as one node of two launches (csrc/hsmssd_v2.inc).  x feeds the norm AND the blend: the blend takes an
+            # alias whose gradient the LayerNorm backward kernel adds in
+            mx = self.mixer
+            y, _, xa = ops.mixer_ln(x.flatten(2), self.norm.weight, self.norm.bias, self.norm.eps, mx.BCdt_proj.conv.weight, mx.dw.conv.weight,
+                                    mx.hz_proj.conv.weight, mx.out_proj.conv.weight, mx.A, mx.D, alias=True)
             x = ops.bn_blend(y, xa.view_as(x), None, a1)
             x = ops.dw_bn_blend(x, self.dwconv2.conv, self.dwconv2.norm, a2)
             return ops.ffn_blend(x, self.ffn.fc1, self.ffn.fc2, a3)

@@ -457,7 +457,8 @@ import os as _os
 K1_MATH = _os.environ.get("KMU_K1_MATH", "bf16x3")
 # K2 forward: "bf16x3" = projection and depthwise 3x3 composed into one 3x3 convolution on the bf16 matrix core
 # (csrc/hsmssd_x3.inc); "f32" = the exact-fp32 projection + LDS stencil kernels (csrc/hsmssd.hip)
-K2_MATH = _os.environ.get("KMU_K2_MATH", "bf16x3")
+#           "v2" (default) = round 4: LayerNorm + HSMSSD forward in two launches (csrc/hsmssd_v2.inc); its backward is the bf16x3 one
+K2_MATH = _os.environ.get("KMU_K2_MATH", "v2")
 _GRID_OK = {}
 
 
@@ -736,8 +737,42 @@ def _hsm_pack(ok, w_bcdt, w_dw, C, st):
                    lambda buf: _lib.check(lib.kmu_hsmssd_pack_x3(_ptr(w_bcdt), _ptr(w_dw), _ptr(buf), C, 1, st), "kmu_hsmssd_pack_x3"))
 
 
+def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, defer):
+    """Backward of HSMSSD.forward given the (normalised) input x, the saved gate state and dy / dh: three launches (pass A, gate,
+    pass B) + the deferred column sums of the parameter-gradient partials.  -> dx, (d_bcdt, d_dw, d_hz, d_out, d_D)"""
+    lib = _lib.load()
+    B, C, N, Hs = dims
+    dev = x.device
+    dy = _f32c(dy, "dy") if dy is not None else torch.zeros(B, C, Hs, Hs, device=dev)
+    dh = _f32c(dh, "dh") if dh is not None else None
+    x3 = K2_MATH != "f32"
+    P = (lib.kmu_hsmssd_bwd_partials_x3 if x3 else lib.kmu_hsmssd_bwd_partials)(B, C, Hs)
+    dx = torch.empty_like(x)
+    p_bcdt = torch.empty(P, 3 * N, C, device=dev, dtype=torch.float32)
+    p_dw = torch.empty(P, 3 * N, 9, device=dev, dtype=torch.float32)
+    G = lib.kmu_hsmssd_gate_partials(B)
+    p_hz = torch.empty(G, 2 * C, C, device=dev, dtype=torch.float32)
+    p_out = torch.empty(G, C, C, device=dev, dtype=torch.float32)
+    p_D = torch.empty(G, device=dev, dtype=torch.float32)
+    nbytes = (lib.kmu_hsmssd_bwd_ws_bytes_x3 if x3 else lib.kmu_hsmssd_bwd_ws_bytes)(B, C, N, Hs)
+    ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
+    st = _stream()
+    fn, tail = lib.kmu_hsmssd_bwd_stage, (st,)
+    if x3:
+        fn, tail = lib.kmu_hsmssd_bwd_stage_x3_pk, (1, _ptr(_hsm_pack(pack_ok, w_bcdt, w_dw, C, st)), st)
+    for stage, nm in enumerate(("hsmssd_bwd_passA", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
+        _lib.check(_call((nm + ("_x3" if x3 and stage == 0 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
+                         _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
+                         _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, *tail), "kmu_hsmssd_bwd_stage")
+    mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    d_bcdt, d_dw, d_hz, d_out, d_D = mk(3 * N, C), mk(3 * N, 9), mk(2 * C, C), mk(C, C), mk(1)
+    _wgrad(lambda: colsum(p_bcdt, p_dw, p_hz, p_out, p_D.view(G, 1), outs=[d_bcdt, d_dw, d_hz, d_out, d_D]), defer)
+    return dx, (d_bcdt.view(3 * N, C, 1), d_dw.view(3 * N, 1, 3, 3), d_hz.view(2 * C, C, 1), d_out.view(C, C, 1), d_D.view(1))
+
+
 class HsmssdFn(torch.autograd.Function):
-    """(y[B,C,Hs,Hs], h[B,C,N]) = HSMSSD(x[B,C,L])  (efficient_vim_init.py:33-61)."""
+    """(y[B,C,Hs,Hs], h[B,C,N]) = HSMSSD(x[B,C,L])  (efficient_vim_init.py:33-61), the round-2 / round-1 kernels:
+    K2_MATH "bf16x3" (csrc/hsmssd_x3.inc) or "f32" (csrc/hsmssd.hip); the default forward is MixerFn (csrc/hsmssd_v2.inc)."""
 
     @staticmethod
     def forward(ctx, x, w_bcdt, w_dw, w_hz, w_out, A, D):
@@ -759,7 +794,7 @@ class HsmssdFn(torch.autograd.Function):
         nbytes = lib.kmu_hsmssd_fwd_ws_bytes(B, C, N, Hs)
         ws = torch.empty(max(1, nbytes // 4), device=dev, dtype=torch.float32)
         st = _stream()
-        x3 = K2_MATH == "bf16x3"
+        x3 = K2_MATH != "f32"
         fn, tail = lib.kmu_hsmssd_fwd_stage, (st,)
         if x3:      # composite-weight pack: per step when the weights are Parameters inside a pack_scope, else made here
             fn, tail = lib.kmu_hsmssd_fwd_stage_x3_pk, (1, _ptr(_hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st)), st)
@@ -776,42 +811,135 @@ class HsmssdFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dh):
-        lib = _lib.load()
         x, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
-        B, C, N, Hs = ctx.dims
-        dev = x.device
-        dy = _f32c(dy, "dy") if dy is not None else torch.zeros(B, C, Hs, Hs, device=dev)
-        dh = _f32c(dh, "dh") if dh is not None else None
-        x3 = K2_MATH == "bf16x3"
-        P = (lib.kmu_hsmssd_bwd_partials_x3 if x3 else lib.kmu_hsmssd_bwd_partials)(B, C, Hs)
-        dx = torch.empty_like(x)
-        p_bcdt = torch.empty(P, 3 * N, C, device=dev, dtype=torch.float32)
-        p_dw = torch.empty(P, 3 * N, 9, device=dev, dtype=torch.float32)
-        G = lib.kmu_hsmssd_gate_partials(B)
-        p_hz = torch.empty(G, 2 * C, C, device=dev, dtype=torch.float32)
-        p_out = torch.empty(G, C, C, device=dev, dtype=torch.float32)
-        p_D = torch.empty(G, device=dev, dtype=torch.float32)
-        nbytes = (lib.kmu_hsmssd_bwd_ws_bytes_x3 if x3 else lib.kmu_hsmssd_bwd_ws_bytes)(B, C, N, Hs)
-        ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
-        st = _stream()
-        fn, tail = lib.kmu_hsmssd_bwd_stage, (st,)
-        if x3:
-            fn, tail = lib.kmu_hsmssd_bwd_stage_x3_pk, (1, _ptr(_hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st)), st)
-        for stage, nm in enumerate(("hsmssd_bwd_passA", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
-            _lib.check(_call((nm + ("_x3" if x3 and stage == 0 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
-                             _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
-                             _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, *tail), "kmu_hsmssd_bwd_stage")
+        dx, (d_bcdt, d_dw, d_hz, d_out, d_D) = _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, ctx.dims, ctx.pack_ok,
+                                                                ctx.defer_wgrad)
         # softmax_L(dt + A[n]) is shift invariant => dL/dA == 0 exactly (the reference's autograd
         # returns ~1e-7 rounding noise here)
-        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        d_bcdt, d_dw, d_hz, d_out, d_D = mk(3 * N, C), mk(3 * N, 9), mk(2 * C, C), mk(C, C), mk(1)
-        _wgrad(lambda: colsum(p_bcdt, p_dw, p_hz, p_out, p_D.view(G, 1), outs=[d_bcdt, d_dw, d_hz, d_out, d_D]), ctx.defer_wgrad)
-        return (dx, d_bcdt.view(3 * N, C, 1), d_dw.view(3 * N, 1, 3, 3), d_hz.view(2 * C, C, 1), d_out.view(C, C, 1),
-                ctx.zero_A, d_D.view(1))
+        return dx, d_bcdt, d_dw, d_hz, d_out, ctx.zero_A, d_D
+
+
+# ticket words of the last-arriver gate (csrc/hsmssd_v2.inc): zero-initialised once, left zero by every launch; each call takes the
+# next B words of the ring, so launches in flight on different streams never share a counter
+_TICKETS = {}
+
+
+def _tickets(dev, n):
+    ent = _TICKETS.get(dev.index)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("kmunet: the first mixer call of a process must not be inside a hipGraph capture (ticket ring allocation)")
+        ent = _TICKETS[dev.index] = [torch.zeros(1 << 16, device=dev, dtype=torch.int32), 0]
+    pool, cur = ent
+    if cur + n > pool.numel():
+        cur = 0
+    ent[1] = cur + n
+    return pool[cur:cur + n]
+
+
+class MixerFn(torch.autograd.Function):
+    """(y[B,C,Hs,Hs], h[B,C,N][, x']) = HSMSSD(LayerNorm1D(x))  -- vim_utils_init.py:50-59 + efficient_vim_init.py:33-61 in TWO launches
+    (csrc/hsmssd_v2.inc: LayerNorm folded into both passes' staging, the gate stage run by the last-arriving workgroup of pass 1,
+    pass 2 as a per-sample dense 3x3).  ln_weight None: no LayerNorm (x is the mixer's input as it is).  alias: a third output
+    aliasing x whose gradient the LayerNorm backward kernel adds in (EfficientViMBlock blends y with the x it normalised)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w_bcdt, w_dw, w_hz, w_out, A, D, alias=False):
+        lib = _lib.load()
+        xin = x
+        x = _f32c(x, "x")
+        B, C, L = x.shape
+        Hs = int(round(L ** 0.5))
+        if Hs * Hs != L:
+            raise RuntimeError("HSMSSD: L=%d is not a perfect square (reference: int(math.sqrt(L)))" % L)
+        N = A.shape[0]
+        origs = (w_bcdt, w_dw)
+        w_bcdt, w_dw = _f32c(w_bcdt, "BCdt_proj.weight").reshape(3 * N, C), _f32c(w_dw, "dw.weight").reshape(3 * N, 9)
+        ctx.pack_ok = _pack_ok(origs, (w_bcdt, w_dw))
+        w_hz, w_out, D = _f32c(w_hz, "hz_proj.weight").reshape(2 * C, C), _f32c(w_out, "out_proj.weight").reshape(C, C), _f32c(D, "D")
+        dev = x.device
+        ln = ln_w is not None
+        need_bwd = any(ctx.needs_input_grad)
+        lw = lb = xn = stats = None
+        if ln:
+            lw, lb = _f32c(ln_w, "norm.weight").reshape(-1), _f32c(ln_b, "norm.bias").reshape(-1)
+            if need_bwd:          # the backward kernels read the normalised x; inference skips the store
+                xn = torch.empty_like(x)
+                stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32)
+        y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
+        h = torch.empty(B, C, N, device=dev, dtype=torch.float32)
+        state = torch.empty(lib.kmu_hsmssd_state_elems(B, C, N), device=dev, dtype=torch.float32)
+        nbytes = lib.kmu_mixer_fwd_ws_bytes(B, C, N, Hs)
+        ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
+        st = _stream()
+        wpk = _hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st)
+        tk = _tickets(dev, B)
+        for stage, nm in enumerate(("hsmssd_fwd_pass1_v2", "hsmssd_fwd_pass2_v2")):
+            _lib.check(_call((nm, (B, C, Hs)), lib.kmu_mixer_fwd_stage, _ptr(x), _ptr(lw), _ptr(lb), float(eps), _ptr(w_dw), _ptr(w_hz),
+                             _ptr(w_out), _ptr(D), _ptr(wpk), _ptr(y), _ptr(h), _ptr(state), _ptr(xn), _ptr(stats), _ptr(ws), nbytes,
+                             _ptr(tk), B, C, N, Hs, stage, 1, st), "kmu_mixer_fwd_stage")
+        ctx.ln = ln
+        if ln:
+            ctx.save_for_backward(x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state)
+            ctx.lnshape = ln_w.shape
+            ctx.defer_ln = _leaf(ln_w, ln_b)
+        else:
+            ctx.save_for_backward(x, w_bcdt, w_dw, w_hz, w_out, D, state)
+        ctx.set_materialize_grads(False)
+        ctx.dims = (B, C, N, Hs)
+        ctx.defer_wgrad = _leaf(w_bcdt, w_dw, w_hz, w_out, D)
+        ctx.zero_A = _const_zeros(A)
+        if alias:
+            return y, h, xin.view_as(xin)
+        return y, h
+
+    @staticmethod
+    def backward(ctx, dy, dh, dalias=None):
+        lib = _lib.load()
+        if ctx.ln:
+            x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+        else:
+            x, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+            xn = x
+        B, C, N, Hs = ctx.dims
+        if dy is None and dh is None:                 # only the alias was used
+            return (dalias,) + (None,) * 10
+        dxn, (d_bcdt, d_dw, d_hz, d_out, d_D) = _hsmssd_backward(xn, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, ctx.dims, ctx.pack_ok,
+                                                                 ctx.defer_wgrad)
+        if not ctx.ln:
+            if dalias is not None:
+                dxn = dxn + dalias
+            return dxn, None, None, None, d_bcdt, d_dw, d_hz, d_out, ctx.zero_A, d_D, None
+        L = Hs * Hs
+        addend = None if dalias is None else _f32c(dalias, "grad of the alias")
+        rows = lib.kmu_layernorm1d_partials(B, C, L)
+        dx = torch.empty_like(x)
+        dwp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
+        dbp = torch.empty(rows, C, device=x.device, dtype=torch.float32)
+        _lib.check(_call(("layernorm1d_bwd", (B, C, L)), lib.kmu_layernorm1d_bwd_add, _ptr(x), _ptr(lw), _ptr(stats), _ptr(dxn), _ptr(addend),
+                         _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, L, 1, _stream()), "kmu_layernorm1d_bwd_add")
+        dw, db = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
+        _wgrad(lambda: colsum(dwp, dbp, outs=[dw, db]), ctx.defer_ln)
+        return dx, dw.view(ctx.lnshape), db.view(ctx.lnshape), None, d_bcdt, d_dw, d_hz, d_out, ctx.zero_A, d_D, None
 
 
 def hsmssd(x, w_bcdt, w_dw, w_hz, w_out, A, D):
+    if K2_MATH == "v2":
+        return MixerFn.apply(x, None, None, 0.0, w_bcdt, w_dw, w_hz, w_out, A, D)
     return HsmssdFn.apply(x, w_bcdt, w_dw, w_hz, w_out, A, D)
+
+
+def mixer_ln(x, ln_w, ln_b, eps, w_bcdt, w_dw, w_hz, w_out, A, D, alias=False):
+    """HSMSSD(LayerNorm1D(x)) -> (y, h[, x']); K2_MATH "v2" (default): two launches, otherwise the LayerNorm kernel + the older forward."""
+    if K2_MATH == "v2":
+        if alias and not (torch.is_grad_enabled() and x.requires_grad):
+            y, h = MixerFn.apply(x, ln_w, ln_b, eps, w_bcdt, w_dw, w_hz, w_out, A, D)
+            return y, h, x
+        return MixerFn.apply(x, ln_w, ln_b, eps, w_bcdt, w_dw, w_hz, w_out, A, D, alias)
+    if alias:
+        xn, xa = layernorm1d_alias(x, ln_w, ln_b, eps)
+        return HsmssdFn.apply(xn, w_bcdt, w_dw, w_hz, w_out, A, D) + (xa,)
+    return HsmssdFn.apply(layernorm1d(x, ln_w, ln_b, eps), w_bcdt, w_dw, w_hz, w_out, A, D)
 
 
 # ------------------------------------------------------------------------------------------ K3

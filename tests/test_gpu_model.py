@@ -74,6 +74,73 @@ def test_whole_model_golden(name, variant, nc, train):
     assert ok, ties.describe_masks(rep)
 
 
+def test_whole_model_at_bench_shape_vs_oracle():
+    """The shape bench.py times -- KM_UNetV3_SH(num_classes=5) at [8,5,128,128], train mode (batch-statistics BatchNorm), through the
+    step's own machinery: the pack scope with the once-per-step packs, the branch streams at 128x128 / 64x64, the stacked 32x32
+    pass, the fused FFN / dwconv stages, the weight-gradient jobs on their side streams -- against oracle.model computed here
+    (KM_UNetV3_SH.py:465-517): output, loss, input gradient and all 664 parameter gradients.  DropPath off on both sides (its
+    draws are not comparable).  Gradients go through the tie allowance of oracle/ties.py exactly as test_whole_model_golden:
+    every ReLU branch that differs from the fp64 oracle's must sit within 5e-5 of zero relative to its layer, and with the
+    same branches every tensor must agree to 2e-3 of its own maximum."""
+    import km_unet_amd
+    from km_unet_amd import ops
+    from km_unet_amd.train import TrainStep, split_frames
+    from oracle import ties
+    from oracle.model import KM_UNetV3 as Oracle, fill_parameters
+    o = fill_parameters(Oracle(num_classes=5), 7).train()
+    m = km_unet_amd.KM_UNetV3(num_classes=5)
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.cuda().train()
+    for net in (o, m):
+        for sub in net.modules():
+            if hasattr(sub, "drop_prob"):
+                sub.drop_prob = 0.0
+    gen = torch.Generator().manual_seed(77)
+    data = torch.rand(8, 10, 1, 128, 128, generator=gen)
+    xo, tgt = split_frames(data)
+    xo.requires_grad_(True)
+    yo = o(xo)
+    lo = torch.nn.functional.mse_loss(yo, tgt)
+    lo.backward()
+    ref = {"<input>": xo.grad}
+    ref.update({k: p.grad for k, p in o.named_parameters() if p.grad is not None})
+
+    step = TrainStep(m, data.cuda(), loss="mse")            # flat parameters + the live-parameter bucket, as bench.py
+    name_of = {id(p): k for k, p in m.named_parameters()}
+    inp, tg = split_frames(data.cuda())
+    inp.requires_grad_(True)
+    with ops.pack_scope():
+        ops.prepack()
+        y, masks = ties.collect_gpu_relu_masks(m, lambda: m(inp))
+        loss = torch.nn.functional.mse_loss(y, tg)
+        ops.WGRAD_OVERLAP = True
+        try:
+            grads = torch.autograd.grad(loss, [inp] + step.dp.bucket.params)
+        finally:
+            ops.WGRAD_OVERLAP = False
+            ops.flush_wgrad_jobs(final=True)
+    torch.cuda.synchronize()
+    got = {"<input>": grads[0].cpu()}
+    got.update({name_of[id(p)]: g.cpu() for p, g in zip(step.dp.bucket.params, grads[1:])})
+    assert sorted(got) == sorted(ref) and len(got) == 665
+    e_y = rel_err(y, yo)
+    worst = max(((k, rel_err(got[k], ref[k])) for k in got if ref[k].numel() > 1 and not k.endswith(".A")), key=lambda t: t[1])
+    print("  [bench shape] y=%.2e loss gpu %.7f cpu %.7f  dx=%.2e  worst grad (max-norm) %s %.2e" % (
+        e_y, loss.item(), lo.item(), rel_err(got["<input>"], ref["<input>"]), worst[0][-48:], worst[1]))
+    assert e_y < TOL and abs(loss.item() - lo.item()) < 1e-5
+    if worst[1] < TOL:
+        return
+    o64 = fill_parameters(Oracle(num_classes=5), 7).double().train()
+    for sub in o64.modules():
+        if hasattr(sub, "drop_prob"):
+            sub.drop_prob = 0.0
+    tgt64 = tgt.double()
+    ok, rep = ties.explain_by_masks(o64, xo.detach().double(), lambda out: torch.nn.functional.mse_loss(out, tgt64), got, masks,
+                                    tie_rel=5e-5, tol=2e-3)
+    print("  [bench shape] tie analysis: %s" % ties.describe_masks(rep))
+    assert ok, ties.describe_masks(rep)
+
+
 @pytest.mark.parametrize("variant,nc,shape", [("LAPS", 7, (1, 5, 256, 256)), ("SH", 5, (1, 5, 256, 256))])
 def test_model_matches_oracle_at_256(variant, nc, shape):
     """configs[3]: the LAPS model at 256x256 (T=12 => num_classes 7; no DAGEM / DySample there, KM_UNetV3_LAPS.py), and the
