@@ -1056,4 +1056,11 @@ extern "C" int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const
 }
 
 // tools only: force the tile height of pass 1 (rows per lane group: 1, 2 or 4; 0 = choose by grid size)
-extern "C" void kmu_mixer_debug_rows(int rows) { g_v2_rows_override = (rows == 1 || rows == 2 || rows == 4) ? rows : 0; }
+extern "C" void kmu_mixer_debug_rows(int rows) {
+    g_v2_dbg = rows >> 8;                      // bit 8: skip the gate tail; bit 9: skip pass 1's main loop; bit 10: phase stamps into `state`
+                                               // (timing experiments: wrong results)
+    rows &= 255;                               // H | 16 (8-wave workgroups) | 32 (wide tiles: 4H x 32, needs 16)
+    const int H = rows & 15;
+    const bool ok = (rows & 32) ? ((rows & 16) && (H == 1 || H == 2 || H == 4)) : ((rows & 16) ? (H == 1 || H == 2) : (H == 1 || H == 2 || H == 4));
+    g_v2_cfg_override = ok ? rows : 0;
+}

@@ -181,6 +181,108 @@ class HsmssdGFn(torch.autograd.Function):
                 ctx.zero_A, d_D.view(G))
 
 
+class MixerGFn(torch.autograd.Function):
+    """(y [B*G, C, Hs, Hs], x') = HSMSSD(LayerNorm1D(x [B*G, C, L])) with G weight sets (sample b: set b % G), the two launches of
+    csrc/hsmssd_v2.inc (ops.MixerFn, grouped); x' aliases x for the blend that follows: its gradient is added inside the LayerNorm
+    backward kernel.  Backward = the grouped bf16x3 HSMSSD backward + the grouped LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w_bcdt, w_dw, w_hz, w_out, A, D):
+        lib = _lib.load()
+        xin = x
+        x = _f32c(x, "x")
+        B, C, L = x.shape
+        Hs = int(round(L ** 0.5))
+        if Hs * Hs != L:
+            raise RuntimeError("HSMSSD: L=%d is not a perfect square (reference: int(math.sqrt(L)))" % L)
+        N = A.shape[0] // G
+        ctx.defer_wgrad = _leaf(w_bcdt, w_dw, w_hz, w_out, D)
+        ctx.defer_ln = _leaf(ln_w, ln_b)
+        origs = (w_bcdt, w_dw)
+        w_bcdt, w_dw = _f32c(w_bcdt, "BCdt_proj.weight").reshape(G * 3 * N, C), _f32c(w_dw, "dw.weight").reshape(G * 3 * N, 9)
+        ctx.pack_ok = ops._pack_ok(origs, (w_bcdt, w_dw))
+        w_hz, w_out = _f32c(w_hz, "hz_proj.weight").reshape(G * 2 * C, C), _f32c(w_out, "out_proj.weight").reshape(G * C, C)
+        D = _f32c(D, "D").reshape(G)
+        lw, lb = _f32c(ln_w, "norm.weight").reshape(-1), _f32c(ln_b, "norm.bias").reshape(-1)
+        dev = x.device
+        need_bwd = any(ctx.needs_input_grad)
+        xn = torch.empty_like(x) if need_bwd else None
+        stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32) if need_bwd else None
+        y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
+        h = torch.empty(B, C, N, device=dev, dtype=torch.float32)
+        state = torch.empty(lib.kmu_hsmssd_state_elems(B, C, N), device=dev, dtype=torch.float32)
+        nbytes = lib.kmu_mixer_fwd_ws_bytes(B, C, N, Hs)
+        ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
+        st = _stream()
+        wpk = ops._hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st, G)
+        tk = ops._tickets(dev, B)
+        for stage, nm in enumerate(("hsmssd_fwd_pass1_v2", "hsmssd_fwd_pass2_v2")):
+            _lib.check(_call((nm + "_g", (B, C, Hs)), lib.kmu_mixer_fwd_stage, _ptr(x), _ptr(lw), _ptr(lb), float(eps), _ptr(w_dw), _ptr(w_hz),
+                             _ptr(w_out), _ptr(D), _ptr(wpk), _ptr(y), _ptr(h), _ptr(state), _ptr(xn), _ptr(stats), _ptr(ws), nbytes,
+                             _ptr(tk), B, C, N, Hs, stage, G, st), "kmu_mixer_fwd_stage")
+        ctx.save_for_backward(x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state)
+        ctx.set_materialize_grads(False)
+        ctx.dims = (B, C, N, Hs)
+        ctx.zero_A = ops._const_zeros(A)
+        ctx.lnshape = ln_w.shape
+        return y, xin.view_as(xin)
+
+    @staticmethod
+    def backward(ctx, dy, dalias):
+        lib = _lib.load()
+        x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+        B, C, N, Hs = ctx.dims
+        L = Hs * Hs
+        dev = x.device
+        if dy is None:
+            return (dalias,) + (None,) * 9
+        dy = _f32c(dy, "dy")
+        P = lib.kmu_hsmssd_bwd_partials_x3(B, C, Hs)
+        dxn = torch.empty_like(x)
+        p_bcdt = torch.empty(P, 3 * N, C, device=dev, dtype=torch.float32)
+        p_dw = torch.empty(P, 3 * N, 9, device=dev, dtype=torch.float32)
+        Gp = lib.kmu_hsmssd_gate_partials(B)
+        p_hz = torch.empty(Gp, 2 * C, C, device=dev, dtype=torch.float32)
+        p_out = torch.empty(Gp, C, C, device=dev, dtype=torch.float32)
+        p_D = torch.empty(Gp, device=dev, dtype=torch.float32)
+        nbytes = lib.kmu_hsmssd_bwd_ws_bytes_x3_g(B, C, N, Hs, G)
+        ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
+        st = _stream()
+        wpk = ops._hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st, G)
+        for stage, nm in enumerate(("hsmssd_bwd_passA_x3", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):
+            _lib.check(_call((nm + "_g", (B, C, Hs)), lib.kmu_hsmssd_bwd_stage_x3_pk, _ptr(xn), _ptr(dy), None, _ptr(w_bcdt), _ptr(w_dw),
+                             _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dxn), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz), _ptr(p_out),
+                             _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, G, _ptr(wpk), st), "kmu_hsmssd_bwd_stage_x3_pk")
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        d_bcdt, d_dw, d_hz, d_out, d_D = mk(G, 3 * N * C), mk(G, 3 * N * 9), mk(G, 2 * C * C), mk(G, C * C), mk(G)
+        Bs, tb, gp = B // G, P // B, Gp // B    # partial rows are (sample b, tile / gate block): the group of a row is b % G
+
+        def job():
+            torch.sum(p_bcdt.view(Bs, G, tb, -1), dim=(0, 2), out=d_bcdt)
+            torch.sum(p_dw.view(Bs, G, tb, -1), dim=(0, 2), out=d_dw)
+            torch.sum(p_hz.view(Bs, G, gp, -1), dim=(0, 2), out=d_hz)
+            torch.sum(p_out.view(Bs, G, gp, -1), dim=(0, 2), out=d_out)
+            torch.sum(p_D.view(Bs, G, gp), dim=(0, 2), out=d_D)
+        _wgrad(job, ctx.defer_wgrad)
+        # LayerNorm1D backward, the blend partner's gradient added in its epilogue
+        addend = None if dalias is None else _f32c(dalias, "grad of the alias")
+        rows = lib.kmu_layernorm1d_partials(B, C, L)
+        dx = torch.empty_like(x)
+        dwp = torch.empty(rows, C, device=dev, dtype=torch.float32)
+        dbp = torch.empty(rows, C, device=dev, dtype=torch.float32)
+        _lib.check(_call(("layernorm1d_bwd_g", (B, C, L)), lib.kmu_layernorm1d_bwd_add, _ptr(x), _ptr(lw), _ptr(stats), _ptr(dxn), _ptr(addend),
+                         _ptr(dx), _ptr(dwp), _ptr(dbp), B, C, L, G, st), "kmu_layernorm1d_bwd_add")
+        dw, db = mk(G, C), mk(G, C)
+        nb = rows // B                      # partial rows are (sample b, block): group of a row = b % G
+
+        def lnjob():
+            torch.sum(dwp.view(B // G, G, nb, C), dim=(0, 2), out=dw)
+            torch.sum(dbp.view(B // G, G, nb, C), dim=(0, 2), out=db)
+        _wgrad(lnjob, ctx.defer_ln)
+        return (dx, dw.view(ctx.lnshape), db.view(ctx.lnshape), None, d_bcdt.view(G * 3 * N, C, 1), d_dw.view(G * 3 * N, 1, 3, 3),
+                d_hz.view(G * 2 * C, C, 1), d_out.view(G * C, C, 1), ctx.zero_A, d_D.view(G))
+
+
 # ------------------------------------------------------------------------------------------ pointwise convs, grouped
 def _pw_fwd_g(lib, x, w, bias, ci, co, act_in=0):
     B, _, H, W = x.shape
@@ -401,12 +503,16 @@ def direction_branches(blocks, xs):
     g, bta, rm, rv, mom, eps, tr = _bn_stacked([e.dwconv1.norm for e in ev])
     x = ops.DwBnBlendFn.apply(x, stack_params([e.dwconv1.conv.weight for e in ev]), g, bta, A4[0], rm, rv, mom, eps, tr, None)
     ln_w, ln_b = stack_params([e.norm.weight for e in ev]), stack_params([e.norm.bias for e in ev])
-    y = LayerNorm1dGFn.apply(x.view(B * G, C, H * W), ln_w, ln_b, ev[0].norm.eps)
     mx = [e.mixer for e in ev]
-    y = HsmssdGFn.apply(y, stack_params([m.BCdt_proj.conv.weight for m in mx]), stack_params([m.dw.conv.weight for m in mx]),
-                        stack_params([m.hz_proj.conv.weight for m in mx]), stack_params([m.out_proj.conv.weight for m in mx]),
-                        stack_params([m.A for m in mx]), stack_params([m.D for m in mx]))
-    x = ops.bn_blend(y.view(B, G * C, H, W), x, None, A4[1])
+    mw = (stack_params([m.BCdt_proj.conv.weight for m in mx]), stack_params([m.dw.conv.weight for m in mx]),
+          stack_params([m.hz_proj.conv.weight for m in mx]), stack_params([m.out_proj.conv.weight for m in mx]),
+          stack_params([m.A for m in mx]), stack_params([m.D for m in mx]))
+    if ops.K2_MATH == "v2":          # LayerNorm1D + HSMSSD as two launches (csrc/hsmssd_v2.inc); the blend takes the alias of x
+        y, xa = MixerGFn.apply(x.view(B * G, C, H * W), ln_w, ln_b, ev[0].norm.eps, *mw)
+        x = ops.bn_blend(y.view(B, G * C, H, W), xa.view_as(x), None, A4[1])
+    else:
+        y = HsmssdGFn.apply(LayerNorm1dGFn.apply(x.view(B * G, C, H * W), ln_w, ln_b, ev[0].norm.eps), *mw)
+        x = ops.bn_blend(y.view(B, G * C, H, W), x, None, A4[1])
     g, bta, rm, rv, mom, eps, tr = _bn_stacked([e.dwconv2.norm for e in ev])
     x = ops.DwBnBlendFn.apply(x, stack_params([e.dwconv2.conv.weight for e in ev]), g, bta, A4[2], rm, rv, mom, eps, tr, None)
     g1, b1, rm1, rv1, mom1, eps1, tr = _bn_stacked([e.ffn.fc1.norm for e in ev])

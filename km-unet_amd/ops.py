@@ -353,7 +353,7 @@ class PackCache:
     def __init__(self):
         self.enabled = False
         self.epoch = 0
-        self.entries = {}        # key -> [buffer, epoch packed, source tensors (kept alive: the key holds their addresses), job]
+        self.entries = {}        # key -> [buffer, epoch packed, source tensors (kept alive: the key holds their addresses), job, epoch last asked for]
         self.plan = None
         self.dirty = False
 
@@ -373,7 +373,7 @@ class PackCache:
                 tabs.append(None)
                 continue
             host = np.zeros(len(group) * rec, dtype=np.uint8)
-            for i, (buf, _, srcs, job) in enumerate(group):
+            for i, (buf, _, srcs, job, _used) in enumerate(group):
                 if job[0] == "conv":
                     _, which, Cin, Cout, K = job
                     ptrs = [_ptr(t) for t in srcs] + [None] * (3 - len(srcs))
@@ -409,6 +409,17 @@ def prepack():
     pc = _PACKS
     if not pc.enabled or not pc.entries:
         return
+    if not torch.cuda.is_current_stream_capturing():
+        # packs nobody has asked for during the last 8 scopes belong to a model that is gone (or to weights that were replaced
+        # out of place): drop them with their source tensors instead of re-packing them every step for ever
+        dead = [k for k, e in pc.entries.items() if e[4] < pc.epoch - 8]
+        for k in dead:
+            del pc.entries[k]
+        if dead:
+            pc.dirty = True
+            if not pc.entries:
+                pc.plan = None
+                return
     if pc.dirty or pc.plan is None:
         if torch.cuda.is_current_stream_capturing():      # the job table needs a host-to-device copy: packs stay lazy this step
             return
@@ -422,8 +433,11 @@ def prepack():
 
 
 def _pack_ok(origs, convs):
-    """Cacheable: the op was handed Parameters and reads them in place (fp32, contiguous)."""
-    return all(isinstance(o, torch.nn.Parameter) and o.data_ptr() == c.data_ptr() for o, c in zip(origs, convs))
+    """Cacheable: the op was handed Parameters (or grouped.StackParamsFn's zero-copy stack of adjacent Parameters) and reads them in
+    place (fp32, contiguous): the weights keep their address and do not change inside a pack_scope."""
+    def stable(o):
+        return isinstance(o, torch.nn.Parameter) or (type(o.grad_fn).__name__ == "StackParamsFnBackward" and o._is_view())
+    return all(stable(o) and o.data_ptr() == c.data_ptr() for o, c in zip(origs, convs))
 
 
 def _packed(ok, srcs, nelems, job, pack_fn):
@@ -440,8 +454,9 @@ def _packed(ok, srcs, nelems, job, pack_fn):
             buf = torch.empty(nelems, device=srcs[0].device, dtype=torch.bfloat16)
             pack_fn(buf)
             return buf
-        e = pc.entries[key] = [torch.empty(nelems, device=srcs[0].device, dtype=torch.bfloat16), -1, tuple(srcs), job]
+        e = pc.entries[key] = [torch.empty(nelems, device=srcs[0].device, dtype=torch.bfloat16), -1, tuple(srcs), job, pc.epoch]
         pc.dirty = True
+    e[4] = pc.epoch
     if e[1] != pc.epoch:
         pack_fn(e[0])
         e[1] = pc.epoch
@@ -731,10 +746,10 @@ def layernorm1d_alias(x, weight, bias, eps=1e-5):
     return LayerNorm1dFn.apply(x, weight, bias, eps, True)
 
 
-def _hsm_pack(ok, w_bcdt, w_dw, C, st):
+def _hsm_pack(ok, w_bcdt, w_dw, C, st, groups=1):
     lib = _lib.load()
-    return _packed(ok, (w_bcdt, w_dw), lib.kmu_hsmssd_pack_elems(C, 1), ("hsm", C, 1),
-                   lambda buf: _lib.check(lib.kmu_hsmssd_pack_x3(_ptr(w_bcdt), _ptr(w_dw), _ptr(buf), C, 1, st), "kmu_hsmssd_pack_x3"))
+    return _packed(ok, (w_bcdt, w_dw), lib.kmu_hsmssd_pack_elems(C, groups), ("hsm", C, groups),
+                   lambda buf: _lib.check(lib.kmu_hsmssd_pack_x3(_ptr(w_bcdt), _ptr(w_dw), _ptr(buf), C, groups, st), "kmu_hsmssd_pack_x3"))
 
 
 def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, defer):

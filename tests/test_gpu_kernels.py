@@ -220,11 +220,13 @@ def test_k2_golden_fused_layernorm(name):
     assert torch.equal(y2, y) and torch.equal(h2, h)
 
 
-@pytest.mark.parametrize("B,C,Hs,rows", [(8, 16, 128, 0), (2, 16, 32, 4), (2, 16, 32, 1), (8, 32, 64, 0), (2, 32, 64, 4), (3, 32, 20, 2), (24, 64, 32, 0),
-                                         (2, 64, 32, 4), (2, 64, 12, 2), (1, 16, 37, 0), (1, 32, 60, 0), (1, 64, 15, 1)])
+@pytest.mark.parametrize("B,C,Hs,rows", [(8, 16, 128, 0), (2, 16, 32, 4), (2, 16, 32, 1), (2, 16, 32, 17), (3, 16, 64, 18), (8, 32, 64, 0), (2, 32, 64, 4),
+                                         (3, 32, 20, 2), (8, 32, 64, 17), (2, 32, 40, 18), (24, 64, 32, 0), (2, 64, 32, 4), (2, 64, 12, 2), (24, 64, 32, 17),
+                                         (3, 64, 20, 18), (3, 64, 32, 18), (1, 16, 37, 0), (1, 32, 60, 0), (1, 64, 15, 1), (1, 16, 9, 17), (2, 16, 200, 0),
+                                         (8, 16, 128, 52), (2, 16, 40, 52), (3, 32, 64, 50), (2, 32, 20, 49), (2, 64, 32, 49), (3, 64, 40, 50), (1, 16, 300, 52)])
 def test_mixer_ln_vs_oracle(B, C, Hs, rows):
-    """The fused forward at the bench shapes and at ragged token grids, every tile height of pass 1 (rows per lane group 1 / 2 / 4;
-    0 = the launcher's choice), against the fp32 oracle (LayerNorm -> HSMSSD) -- and its own two launches run twice are bit-identical
+    """The fused forward at the bench shapes and at ragged token grids, every configuration of pass 1 (rows per lane group 1 / 2 / 4,
+    + 16 = 8-wave workgroups, + 32 = 32-column tiles; 0 = the launcher's choice; T > 64 tiles per sample = several combine chunks), against the fp32 oracle (LayerNorm -> HSMSSD) -- and its own two launches run twice are bit-identical
     (tiles are combined in tile order by whichever workgroup arrives last; no float atomics)."""
     from oracle import hsmssd as oh
     from km_unet_amd import _lib
@@ -320,9 +322,9 @@ def test_k2_softmax_stability_and_shift_invariance():
     y1, h1 = ops.hsmssd(x, w_bcdt, w_dw, w_hz, w_out, torch.zeros(N, device=DEV), D)
     y2, h2 = ops.hsmssd(x, w_bcdt, w_dw, w_hz, w_out, torch.full((N,), 1e4, device=DEV), D)
     assert torch.isfinite(y1).all() and torch.equal(y1, y2) and torch.equal(h1, h2)
-    # batch independence
+    # batch independence (the forward picks its token tiling by grid size: a one-sample run may sum in another order, ~1e-6)
     y3, _ = ops.hsmssd(x[2:3].contiguous(), w_bcdt, w_dw, w_hz, w_out, torch.zeros(N, device=DEV), D)
-    assert rel_err(y3, y1[2:3]) < 1e-6
+    assert rel_err(y3, y1[2:3]) < 2e-5
 
 
 @pytest.mark.parametrize("B,C,Hs", [(2, 16, 32), (8, 16, 128), (2, 32, 64), (8, 32, 64), (2, 64, 32), (8, 64, 32), (1, 32, 20), (3, 64, 12),
@@ -381,7 +383,8 @@ def test_k2_large_image_properties(B, C, Hs):
     x1 = x[B - 1:].detach().contiguous().requires_grad_(True)
     y1, _ = ops.hsmssd(x1, *w)
     (dx1,) = torch.autograd.grad((y1 * gy[B - 1:]).sum(), x1)
-    assert rel_err(y1, y[B - 1:]) < 1e-6 and rel_err(dx1, dx[B - 1:]) < 1e-5
+    # (the forward picks its token tiling by grid size, so the one-sample run may sum in another order: fp32 reassociation, ~3e-6)
+    assert rel_err(y1, y[B - 1:]) < 2e-5 and rel_err(dx1, dx[B - 1:]) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------ K3

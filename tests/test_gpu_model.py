@@ -79,9 +79,12 @@ def test_whole_model_at_bench_shape_vs_oracle():
     step's own machinery: the pack scope with the once-per-step packs, the branch streams at 128x128 / 64x64, the stacked 32x32
     pass, the fused FFN / dwconv stages, the weight-gradient jobs on their side streams -- against oracle.model computed here
     (KM_UNetV3_SH.py:465-517): output, loss, input gradient and all 664 parameter gradients.  DropPath off on both sides (its
-    draws are not comparable).  Gradients go through the tie allowance of oracle/ties.py exactly as test_whole_model_golden:
-    every ReLU branch that differs from the fp64 oracle's must sit within 5e-5 of zero relative to its layer, and with the
-    same branches every tensor must agree to 2e-3 of its own maximum."""
+    draws are not comparable).  Gradients go through the tie allowance of oracle/ties.py as in test_whole_model_golden: every ReLU
+    branch that differs from the fp64 oracle's must sit within 1e-4 of zero relative to its layer's largest pre-activation, and
+    with the same branches every tensor must agree to 2e-3 of its own maximum.  (1e-4 here against 5e-5 at the 2 x 64 x 64 fixture:
+    this input has 128 times the ReLU elements, so the furthest flip among them lies further out -- observed 972 flips in 19
+    layers, the furthest at 4.9e-5; the split-bf16 products move a pre-activation by ~1e-5 of its summands, and a layer's largest
+    pre-activation is a few of those.  Same-branch gradients: 5.0e-4 observed.)"""
     import km_unet_amd
     from km_unet_amd import ops
     from km_unet_amd.train import TrainStep, split_frames
@@ -136,7 +139,7 @@ def test_whole_model_at_bench_shape_vs_oracle():
             sub.drop_prob = 0.0
     tgt64 = tgt.double()
     ok, rep = ties.explain_by_masks(o64, xo.detach().double(), lambda out: torch.nn.functional.mse_loss(out, tgt64), got, masks,
-                                    tie_rel=5e-5, tol=2e-3)
+                                    tie_rel=1e-4, tol=2e-3)
     print("  [bench shape] tie analysis: %s" % ties.describe_masks(rep))
     assert ok, ties.describe_masks(rep)
 
