@@ -627,7 +627,8 @@ int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const float* ln_
                         const float* w_out, const float* D, const void* wpk, float* y, float* h, float* state, float* xn,
                         float* rstd_mean, void* ws, size_t ws_bytes, unsigned int* tickets, int B, int C, int N, int Hs, int stage,
                         int groups, kmu_stream_t stream);
-void kmu_mixer_debug_rows(int rows); /* tools only: force pass 1's rows per lane group (1 / 2 / 4; 0 = automatic) */
+void kmu_mixer_debug_rows(int rows); /* tools only: force pass 1's configuration (H | 16: 8 waves | 32: wide tiles; 0 = automatic) */
+void kmu_conv_debug_split(int mode); /* tools only: K1 / KxK forward at small images: 0 automatic, 1 never split Cout tiles over workgroups, 2 always */
 
 /* kmu_hsmssd_{fwd,bwd}_stage_x3_g with the pack handed in (wpk NULL: pack inside stage 0 as before) */
 int kmu_hsmssd_fwd_stage_x3_pk(const float* x, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,

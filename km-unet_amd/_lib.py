@@ -142,6 +142,7 @@ SIGNATURES = {
     "kmu_mixer_fwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_mixer_fwd_stage": (_I, [_P] * 3 + [_c.c_float] + [_P] * 11 + [_Z, _P] + [_I] * 6 + [_P]),
     "kmu_mixer_debug_rows": (None, [_I]),
+    "kmu_conv_debug_split": (None, [_I]),
     "kmu_gate_mlp_fwd_g": (_I, [_P] * 7 + [_I] * 7 + [_P]),
     "kmu_gate_mlp_bwd_g": (_I, [_P] * 11 + [_I] * 7 + [_P]),
     "kmu_mix3_fwd_stacked": (_I, [_P] * 5 + [_I] * 2 + [_P]),

@@ -358,12 +358,21 @@ int launch_fwd(const float* x, const float* knots, const void* wp, const float* 
 
 // tile / wave layout: all Cout channel tiles in one workgroup (the feature tile is evaluated once), enough workgroups to fill
 // 256 CUs where the image allows it
+static int g_conv_split = 0;
 template <int MODE>
 int dispatch_fwd(const float* x, const float* knots, const void* wp, const float* bias, const float* residual, float* y, int B,
                  int Cin, int Cout, int H, int W, int relu, hipStream_t st) {
     const int NT = kmu::cdiv(Cout, 16);
     const long px = (long)B * H * W;
     const bool big = px >= 65536 && W >= 32;
+    // small images (32 x 32 and below at B = 8: 128 tiles of 4 x 16): the output-channel tiles go to separate workgroups (grid.y),
+    // each re-evaluating the feature tile, when that is what it takes to give every CU one (g_split: 0 = automatic, 1 = never, 2 = always)
+    const bool split = !big && NT >= 2 && (g_conv_split == 2 || (g_conv_split == 0 && px / 64 * 2 <= 384));
+    if (split) {
+        if (NT % 2 == 0 && px / 64 * (NT / 2) >= 256 && g_conv_split != 2)
+            return launch_fwd<MODE, 4, 16, 2, 2, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);                // grid.y = NT / 2
+        return launch_fwd<MODE, 4, 16, 4, 1, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);                    // grid.y = NT
+    }
     if (NT == 1) {
         if (big) return launch_fwd<MODE, 8, 32, 4, 1, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
         return launch_fwd<MODE, 4, 16, 4, 1, 1>(x, knots, wp, bias, residual, y, B, Cin, Cout, H, W, relu, st);
@@ -1021,3 +1030,6 @@ extern "C" int kmu_conv3x3_bwd_weight_x3(const float* x, const float* dy, float*
                                          int Cout, int H, int W, kmu_stream_t stream) {
     return kmu_conv2d_bwd_weight_x3(x, dy, d_weight, ws, ws_bytes, B, Cin, Cout, H, W, 3, stream);
 }
+
+// tools only: how the forward splits output-channel tiles over workgroups at small images (0 automatic, 1 never, 2 always)
+extern "C" void kmu_conv_debug_split(int mode) { g_conv_split = (mode >= 0 && mode <= 2) ? mode : 0; }
