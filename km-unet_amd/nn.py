@@ -73,11 +73,9 @@ def _is_pointwise(c):
 
 # ------------------------------------------------------------------ convKAN (K1)
 class KANLinear(nn.Module):
-    """Parameter container compatible with convKAN/KANlayers.py:505-575.
-
-    Used through KANConv2d (the only way KM-UNet uses it).  A direct call treats the rows as
-    1x1 "images" of a 3x3-padded conv is not meaningful, so forward() on a bare [M, in] matrix
-    is provided only for in_features divisible by 9 via the same kernel (centre-tap free)."""
+    """convKAN/KANlayers.py:505-731.  KM-UNet uses it through KANConv2d, which runs the layer on the HIP kernels (csrc/conv3x3_x3.hip /
+    kan_conv2d.hip); the row-wise methods below (b_splines, forward, curve2coeff, update_grid) are stock tensor arithmetic for API
+    completeness."""
 
     def __init__(self, in_features, out_features, grid_size=5, spline_order=3, scale_noise=0.1, scale_base=1.0,
                  scale_spline=1.0, enable_standalone_scale_spline=True, base_activation=nn.SiLU, grid_eps=0.02,
@@ -95,6 +93,7 @@ class KANLinear(nn.Module):
         self.spline_weight = nn.Parameter(torch.empty(out_features, in_features, grid_size + spline_order))
         self.spline_scaler = nn.Parameter(torch.empty(out_features, in_features))
         self.scale_noise, self.scale_base, self.scale_spline = scale_noise, scale_base, scale_spline
+        self.grid_eps = grid_eps
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -126,12 +125,49 @@ class KANLinear(nn.Module):
         p = a / total
         return regularize_activation * total - regularize_entropy * torch.sum(p * torch.log(p))
 
+    # ---- the row-wise form (KANlayers.py:577-660) in plain tensor arithmetic: needed by update_grid and, after it, by a layer whose
+    # input features no longer share one knot vector.  NOT the accelerated path: KANConv2d runs on the HIP kernels whenever the grid
+    # rows are identical (always, unless update_grid was called -- the reference never calls it).
+    def b_splines(self, x):
+        """[M, in] -> [M, in, grid_size + spline_order]: Cox-de Boor on each feature's own knots, half-open intervals (:577-610)."""
+        g = self.grid
+        x = x.unsqueeze(-1)
+        b = ((x >= g[:, :-1]) & (x < g[:, 1:])).to(x.dtype)
+        for k in range(1, self.spline_order + 1):
+            b = (x - g[:, :-(k + 1)]) / (g[:, k:-1] - g[:, :-(k + 1)]) * b[:, :, :-1] \
+                + (g[:, k + 1:] - x) / (g[:, k + 1:] - g[:, 1:-k]) * b[:, :, 1:]
+        return b.contiguous()
+
+    def curve2coeff(self, x, y):
+        """Least-squares spline coefficients [out, in, coeff] of the curves through (x [M, in], y [M, in, out]) (:612-642)."""
+        sol = torch.linalg.lstsq(self.b_splines(x).transpose(0, 1), y.transpose(0, 1)).solution      # [in, coeff, out]
+        return sol.permute(2, 0, 1).contiguous()
+
+    def forward(self, x):
+        """y = SiLU(x) Wb^T + vec(B(x)) (Ws . scaler)^T on rows [M, in] (:652-660), stock tensor ops on x's device."""
+        base = torch.nn.functional.linear(torch.nn.functional.silu(x), self.base_weight)
+        spline = torch.nn.functional.linear(self.b_splines(x).view(x.size(0), -1), self.scaled_spline_weight.view(self.out_features, -1))
+        return base + spline
+
+    @torch.no_grad()
     def update_grid(self, x, margin=0.01):
-        """KANlayers.py:662-711 re-fits a separate, data-adaptive knot vector per input feature.  The HIP kernels evaluate
-        the basis once per input element against ONE shared knot vector (that is where the 9x saving over the unfolded
-        evaluation comes from), and KM-UNet never calls this method, so it is not provided."""
-        raise NotImplementedError("KANLinear.update_grid: per-feature adaptive knot vectors are not supported by the HIP "
-                                  "kernels (one shared knot vector per layer); KM-UNet does not use it")
+        """KANlayers.py:662-709: re-fit every input feature's knot vector to the distribution of its column of x [M, in] (grid_eps
+        blends a uniform grid over the column's range with its quantiles), then re-fit the spline coefficients so that the layer's
+        spline outputs on x are preserved.  Afterwards the features no longer share one knot vector: KANConv2d then evaluates this
+        layer through `forward` above (unfold + tensor ops) instead of the HIP kernels, which are built for the shared grid."""
+        assert x.dim() == 2 and x.size(1) == self.in_features
+        m = x.size(0)
+        per_feature = torch.bmm(self.b_splines(x).permute(1, 0, 2), self.scaled_spline_weight.permute(1, 2, 0)).permute(1, 0, 2)   # [M, in, out]
+        xs = torch.sort(x, dim=0)[0]
+        adaptive = xs[torch.linspace(0, m - 1, self.grid_size + 1, dtype=torch.int64, device=x.device)]
+        step = (xs[-1] - xs[0] + 2 * margin) / self.grid_size
+        uniform = torch.arange(self.grid_size + 1, dtype=torch.float32, device=x.device).unsqueeze(1) * step + xs[0] - margin
+        grid = self.grid_eps * uniform + (1 - self.grid_eps) * adaptive
+        k = self.spline_order
+        grid = torch.cat([grid[:1] - step * torch.arange(k, 0, -1, device=x.device).unsqueeze(1), grid,
+                          grid[-1:] + step * torch.arange(1, k + 1, device=x.device).unsqueeze(1)], dim=0)
+        self.grid.copy_(grid.T)
+        self.spline_weight.data.copy_(self.curve2coeff(x, per_feature))
 
 
 def _bspline_collocation(x, knots, order):
@@ -156,7 +192,31 @@ class KANConv2d(nn.Module):
 
     def forward(self, x, residual=None, relu=False):
         k = self.kanlayer
+        if not _shared_grid(k.grid):
+            # update_grid() gave every (channel, tap) feature its own knots: Phi can no longer be evaluated once per input element,
+            # which is what the HIP kernels are built on -- the layer runs in its row-wise form (unfold + tensor ops on x's device).
+            # No model of the reference reaches this state (update_grid is never called: SURVEY.md section 7).
+            from .kan_variants import fold_rows, unfold_rows
+            rows, shape = unfold_rows(x, self.kernel_size, self.stride, self.padding)
+            y = fold_rows(k(rows), shape, self.out_channels)
+            if residual is not None:
+                y = y + residual
+            return torch.relu(y) if relu else y
         return ops.kan_conv2d(x, k.grid, k.base_weight, k.spline_weight, k.spline_scaler, residual, relu)
+
+
+_GRID_SHARED = {}
+
+
+def _shared_grid(grid):
+    """True when every row of KANLinear.grid is the same knot vector (checked once per buffer version)."""
+    key = (grid.data_ptr(), grid._version, tuple(grid.shape))
+    v = _GRID_SHARED.get(key)
+    if v is None:
+        if len(_GRID_SHARED) > 256:
+            _GRID_SHARED.clear()
+        v = _GRID_SHARED[key] = bool((grid == grid[0:1]).all())
+    return v
 
 
 # ------------------------------------------------------------------ vim_block_init (K2)

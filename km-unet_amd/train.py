@@ -94,6 +94,16 @@ class GraphedTrainStep:
     `check_loss()` repeats the cheap part (finite, no jump against the previous call) at any later point."""
 
     def __init__(self, step, example_data, warmup=3, validate=True):
+        # The captured step forks ~9 streams (3 direction branches, 2 pyramids, 4 weight-gradient lanes).  With GPU_MAX_HW_QUEUES
+        # below the runtime's default of 4 the HIP runtime (ROCm 7.2) dies with SIGSEGV inside hipGraphLaunch at the FIRST replay
+        # (python -X faulthandler: torch/cuda/graphs.py replay <- _validate; no kernel of ours involved; seen twice with the knob
+        # at 2, rounds 2 and 3) -- a drop-in library inherits its host's environment, so refuse with a message instead.
+        import os
+        q = os.environ.get("GPU_MAX_HW_QUEUES")
+        if q is not None and q.strip().isdigit() and int(q) < 4:
+            raise RuntimeError("GraphedTrainStep: GPU_MAX_HW_QUEUES=%s -- the HIP runtime crashes (SIGSEGV in hipGraphLaunch) when a graph with "
+                               "this step's parallel branches is replayed on fewer than 4 hardware queues; unset the variable (the default "
+                               "is 4, measured fastest) or train with the eager TrainStep" % q)
         self.step = step
         self.static_data = example_data.clone()
         side = torch.cuda.Stream()

@@ -15,6 +15,8 @@ What each fixture pins (reference file:line):
                index-explicit form after it reproduced F.grid_sample's output)
   iwp_*.npz    WPL/iwp.py:116-132
   dagem_plain_*.npz  DAGEM_md.py:56-111 with the deformable conv replaced by a plain conv on both sides
+  kanvar_*.npz convKAN/KANConv2Dlayers.py:40-293 (the eight alternative KAN convolutions: output + input gradient for explicit parameters)
+  kan_update_grid.npz  KANlayers.py:662-709 (update_grid: knots and spline coefficients after the re-fit, layer output before / after)
   model_*.npz  KM_UNetV3_SH.py:465-517 / KM_UNetV3_LAPS.py (DAGEM's deform-conv
                = oracle restatement of torchvision => that sub-block is unpinned)
   manifest_*.txt  state_dict key / shape / dtype lists
@@ -90,6 +92,54 @@ def gen_kan_reg(ref):
     m = ref.kanconv.KANConv2d(4, 8, 3, padding=1).kanlayer
     set_params(m, 77, lambda k, p: 0.2)
     save("kan_reg", spline_weight=m.spline_weight, r11=m.regularization_loss(1.0, 1.0), r03_2=m.regularization_loss(0.3, 2.0))
+
+
+def gen_kan_variants(ref):
+    """The eight alternative KAN convolutions (KANConv2Dlayers.py:40-293) on one small input each, parameters set explicitly."""
+    kw = {"ChebyKANConv2d": {"degree": 4}, "WavKANConv2d": {"wavelet_type": "mexican_hat"}, "JacobiKANConv2d": {"degree": 4}}
+    for si, name in enumerate(("ChebyKANConv2d", "FastKANConv2d", "GRAMKANConv2d", "WavKANConv2d", "JacobiKANConv2d", "ReLUKANConv2d",
+                               "FasterKANConv2d", "RBFKANConv2d")):
+        torch.manual_seed(900 + si)
+        m = getattr(ref.kanconv, name)(3, 5, 3, padding=1, **kw.get(name, {}))
+        m.eval()                                    # WavKAN's BatchNorm1d: running statistics (deterministic)
+        with torch.no_grad():                       # move every trainable tensor off its initial value, keep scales positive
+            for i, (k, p_) in enumerate(sorted(m.named_parameters())):
+                if not p_.requires_grad:
+                    continue
+                p_.add_(rnd(900 * 100 + si * 50 + i, *p_.shape, scale=0.1 if p_.ndim > 0 else 0.0))
+            for k, b_ in m.named_buffers():
+                if k.endswith("running_var"):
+                    b_.copy_(torch.rand(b_.shape, generator=torch.Generator().manual_seed(si)) + 0.5)
+                if k.endswith("running_mean"):
+                    b_.copy_(rnd(si + 5, *b_.shape, scale=0.2))
+        x = rnd(950 + si, 2, 3, 6, 5, scale=0.8).requires_grad_(True)
+        y = m(x)
+        gy = rnd(970 + si, *y.shape)
+        y.backward(gy)
+        sd = {"sd__" + k.replace(".", "__"): v for k, v in m.state_dict().items()}
+        save("kanvar_" + name, x=x, gy=gy, y=y, dx=x.grad, **sd)
+    # the other wavelets of WavKANLayer (KANlayers.py:262-300) share everything but psi: forward only
+    for kind in ("morlet", "dog", "meyer", "shannon"):
+        torch.manual_seed(990)
+        m = ref.kanconv.WavKANConv2d(2, 3, 3, padding=1, wavelet_type=kind).eval()
+        x = rnd(991, 1, 2, 4, 4, scale=0.8)
+        with torch.no_grad():
+            y = m(x)
+        save("kanvar_wav_" + kind, x=x, y=y, **{"sd__" + k.replace(".", "__"): v for k, v in m.state_dict().items()})
+
+
+def gen_update_grid(ref):
+    """KANLinear.update_grid (KANlayers.py:662-709) on explicit parameters and rows."""
+    torch.manual_seed(5)
+    m = ref.kanlayers.KANLinear(6, 4)
+    set_params(m, 81, lambda k, p: 0.3 if "scaler" in k else 0.2)
+    x = rnd(82, 40, 6, scale=0.7)
+    before = dict(grid=m.grid.clone(), spline_weight=m.spline_weight.detach().clone(), base_weight=m.base_weight.detach().clone(),
+                  spline_scaler=m.spline_scaler.detach().clone())
+    y0 = m(x)
+    m.update_grid(x)
+    y1 = m(x)
+    save("kan_update_grid", x=x, y_before=y0, y_after=y1, grid_after=m.grid, spline_weight_after=m.spline_weight, **{k + "_before": v for k, v in before.items()})
 
 
 # ---------------------------------------------------------------- K2
@@ -225,8 +275,14 @@ def gen_model(ref):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ref = ref_loader.load()
+    if "--only-variants" in sys.argv:
+        gen_kan_variants(ref)
+        gen_update_grid(ref)
+        raise SystemExit(0)
     gen_k1(ref)
     gen_kan_reg(ref)
+    gen_kan_variants(ref)
+    gen_update_grid(ref)
     gen_k2(ref)
     gen_evim(ref)
     gen_k3(ref)

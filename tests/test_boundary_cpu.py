@@ -96,21 +96,23 @@ def test_dropin_import_paths():
         "m = KM_UNetV3(num_classes=20); assert len(m.state_dict()) == 920\n"
         "assert 'bridge_attention.deform_conv.weight' not in L(num_classes=3).state_dict()\n"
         "assert KANConv2d(4, 4, 3, padding=1).kanlayer.grid.shape == (36, 12)\n"
+        "import torch\n"
         "for n in 'Cheby Fast GRAM Wav Jacobi ReLU Faster RBF'.split():\n"
-        "    cls = globals()[n + 'KANConv2d']          # KANConv2Dlayers.py:40-293: importable, refused with a reason\n"
-        "    try: cls(4, 4, 3, padding=1); raise SystemExit('constructed ' + n)\n"
-        "    except NotImplementedError as e: assert 'hot path' in str(e)\n"
+        "    m = globals()[n + 'KANConv2d'](4, 6, 3, padding=1)          # KANConv2Dlayers.py:40-293: pass-through PyTorch modules\n"
+        "    assert m(torch.randn(2, 4, 5, 5)).shape == (2, 6, 5, 5)\n"
+        "from convKAN.KANlayers import KANLinear, ChebyKANLayer, FastKANLayer, GRAMLayer, WavKANLayer, JacobiKANLayer, ReLUKANLayer, FasterKANLayer, RBFKANLayer\n"
         "print('ok')\n") % os.path.join(ROOT, "km-unet_amd", "dropin")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_kanlinear_api_completeness():
-    """KANLinear.regularization_loss / scaled_spline_weight (KANlayers.py:644-650,713-731) are parameter-only and run
-    anywhere; update_grid is refused with a reason (per-feature knot vectors)."""
-    import pytest
+    """KANLinear.regularization_loss / scaled_spline_weight (KANlayers.py:644-650,713-731) are parameter-only and run anywhere;
+    update_grid (:662-709) against the REFERENCE's fixture: knots, re-fitted coefficients and the layer's row-wise output before
+    and after; a KANConv2d whose features no longer share a knot vector runs in its row-wise form."""
     import torch
     import km_unet_amd
+    from conftest import load_golden
     from oracle import kan as okan
     torch.manual_seed(3)
     m = km_unet_amd.KANLinear(36, 8)
@@ -122,8 +124,57 @@ def test_kanlinear_api_completeness():
     assert torch.equal(m.scaled_spline_weight, m.spline_weight * m.spline_scaler[..., None])
     m.regularization_loss().backward()
     assert m.spline_weight.grad is not None and m.base_weight.grad is None
-    with pytest.raises(NotImplementedError):
-        m.update_grid(torch.randn(4, 36))
+    g = load_golden("kan_update_grid")
+    k = km_unet_amd.KANLinear(6, 4)
+    with torch.no_grad():
+        k.grid.copy_(g["grid_before"])
+        k.spline_weight.copy_(g["spline_weight_before"])
+        k.base_weight.copy_(g["base_weight_before"])
+        k.spline_scaler.copy_(g["spline_scaler_before"])
+    assert torch.allclose(k(g["x"]), g["y_before"], rtol=1e-5, atol=1e-6)
+    k.update_grid(g["x"])
+    assert torch.allclose(k.grid, g["grid_after"], rtol=1e-5, atol=1e-6)
+    # the re-fit is a least-squares solve (40 rows, 8 unknowns per feature): coefficients to 1e-3, the curve itself tighter
+    assert (k.spline_weight - g["spline_weight_after"]).abs().max() < 1e-3 * g["spline_weight_after"].abs().max()
+    assert torch.allclose(k(g["x"]), g["y_after"], rtol=1e-4, atol=1e-5)
+    # a KANConv2d in that state: per-feature knots => the row-wise pass-through form (any device), not the HIP kernels
+    c = km_unet_amd.KANConv2d(2, 3, 3, padding=1)
+    rows = torch.nn.functional.unfold(torch.randn(4, 2, 5, 5), 3, padding=1).transpose(1, 2).reshape(-1, 18)
+    c.kanlayer.update_grid(rows)
+    assert not bool((c.kanlayer.grid == c.kanlayer.grid[0:1]).all())
+    assert c(torch.randn(1, 2, 4, 4)).shape == (1, 3, 4, 4)
+
+
+@pytest.mark.parametrize("name", ["ChebyKANConv2d", "FastKANConv2d", "GRAMKANConv2d", "WavKANConv2d", "JacobiKANConv2d", "ReLUKANConv2d",
+                                  "FasterKANConv2d", "RBFKANConv2d"])
+def test_kan_variants_match_reference_fixtures(name):
+    """the eight alternative KAN convolutions (KANConv2Dlayers.py:40-293) as pass-through modules -- same constructor,
+    same state_dict keys (strict load of the reference's), output and input gradient against the REFERENCE's fixture."""
+    from conftest import load_golden
+    from km_unet_amd import kan_variants
+    g = load_golden("kanvar_" + name)
+    kw = {"ChebyKANConv2d": {"degree": 4}, "WavKANConv2d": {"wavelet_type": "mexican_hat"}, "JacobiKANConv2d": {"degree": 4}}.get(name, {})
+    m = kan_variants.VARIANTS[name](3, 5, 3, padding=1, **kw).eval()
+    sd = {k[4:].replace("__", "."): v for k, v in g.items() if k.startswith("sd__")}
+    m.load_state_dict(sd, strict=True)
+    x = g["x"].clone().requires_grad_(True)
+    y = m(x)
+    y.backward(g["gy"])
+    ey = ((y - g["y"]).abs().max() / g["y"].abs().max()).item()
+    edx = ((x.grad - g["dx"]).abs().max() / g["dx"].abs().max()).item()
+    assert ey < 1e-5 and edx < 1e-5, (name, ey, edx)
+
+
+@pytest.mark.parametrize("kind", ["morlet", "dog", "meyer", "shannon"])
+def test_wavkan_other_wavelets(kind):
+    from conftest import load_golden
+    from km_unet_amd import kan_variants
+    g = load_golden("kanvar_wav_" + kind)
+    m = kan_variants.WavKANConv2d(2, 3, 3, padding=1, wavelet_type=kind).eval()
+    m.load_state_dict({k[4:].replace("__", "."): v for k, v in g.items() if k.startswith("sd__")}, strict=True)
+    with torch.no_grad():
+        y = m(g["x"])
+    assert ((y - g["y"]).abs().max() / g["y"].abs().max()).item() < 1e-5
 
 
 def test_cosine_annealing_matches_torch_scheduler():

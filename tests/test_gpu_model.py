@@ -496,3 +496,29 @@ def test_reference_style_training_iterations():
     moved = sum(1 for a, p in zip(before, model.parameters()) if not torch.equal(a, p.detach()))
     print("  [reference-style loop] losses %s, %d / %d parameter tensors moved" % (["%.4f" % l for l in losses], moved, len(before)))
     assert all(l == l and l < 10 for l in losses) and moved >= 664
+
+
+def test_graphed_step_refuses_too_few_hw_queues():
+    """GPU_MAX_HW_QUEUES=2 made the HIP runtime die with SIGSEGV inside hipGraphLaunch at the first replay of the captured step (two
+    records, rounds 2 / 3; located with faulthandler in round 4: torch/cuda/graphs.py replay <- GraphedTrainStep._validate).  A child
+    process under that knob must now get a clean RuntimeError from GraphedTrainStep -- and the eager TrainStep must still train."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import km_unet_amd\n"
+        "from km_unet_amd.train import TrainStep, GraphedTrainStep\n"
+        "m = km_unet_amd.KM_UNetV3(num_classes=5).cuda().train()\n"
+        "d = torch.rand(2, 10, 1, 32, 32, device='cuda')\n"
+        "st = TrainStep(m, d, capturable=True, loss='mse')\n"
+        "l = float(st(d)); assert l == l\n"
+        "try:\n"
+        "    GraphedTrainStep(st, d)\n"
+        "    print('BUILT')\n"
+        "except RuntimeError as e:\n"
+        "    print('REFUSED', 'GPU_MAX_HW_QUEUES' in str(e))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "REFUSED True" in r.stdout, (r.stdout, r.stderr[-1000:])
