@@ -257,10 +257,10 @@ __global__ __launch_bounds__(256) void deform_scatter_lds_kernel(const float* __
     const int hw = H * W, b = blockIdx.y, NI = 9 * hw;
     const float* xb = x + (size_t)b * Cin * hw;
     {
-        // LDS: start[hw + 1] | cursor[hw] | wgt[4 NI] | itm[4 NI] (u16)
+        // LDS: start[hw + 1] | cursor[256] (also the 256-thread scan scratch: hw <= 256) | wgt[4 NI] | itm[4 NI] (u16)
         int* start = reinterpret_cast<int*>(scl);
         int* cursor = start + hw + 1;
-        float* wgt = reinterpret_cast<float*>(cursor + hw);
+        float* wgt = reinterpret_cast<float*>(cursor + 256);
         unsigned short* itm = reinterpret_cast<unsigned short*>(wgt + 4 * NI);
         const int c0 = blockIdx.x * SC_CH, nch = min(SC_CH, Cin - c0);
         for (int e = threadIdx.x; e < 2 * hw + 1; e += 256) start[e] = 0;       // start[] doubles as the count array (shifted by one)
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void deform_scatter_lds_kernel(const float* __
 
 inline size_t scatter_lds_bytes(int H, int W) {
     const size_t hw = (size_t)H * W;
-    return (2 * hw + 1) * sizeof(int) + 4 * 9 * hw * (sizeof(float) + sizeof(unsigned short)) + 16;
+    return (hw + 1 + 256) * sizeof(int) + 4 * 9 * hw * (sizeof(float) + sizeof(unsigned short)) + 16;
 }
 
 }  // namespace

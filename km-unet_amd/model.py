@@ -24,7 +24,6 @@ import os as _os
 # (34.1 vs 30.6 ms/step); inside the captured hipGraph the branches become parallel graph branches and their small kernels
 # overlap: 17.16 vs 17.91 ms/step (round 2, B=8).  On by default; KMU_BRANCH_STREAMS=0 serialises them again.
 _BRANCH_STREAMS = _os.environ.get("KMU_BRANCH_STREAMS", "1") == "1"
-_BRANCH_MIN_C = int(_os.environ.get("KMU_BRANCH_MIN_C", "0"))      # fork only levels with at least this many channels
 # KMU_GROUPED_BRANCHES=1: the three direction branches stacked along the channel axis, one launch per layer (grouped.py), instead of
 # three passes on side streams.  Measured on MI355X (B = 8, round 2): 1380 instead of 1837 launches and 14.4 instead of 17.7 ms of
 # serialised kernel time per step -- but 13.5 ms/step against 12.9 for the forked branches (grouped only at C >= 32: 13.0, C >= 64:
@@ -41,17 +40,13 @@ _SIDE = {}
 _PYR = {}
 
 
-_QKV_DW = _os.environ.get("KMU_QKV_DW", "1") == "1"          # DirectionAttention: sigmoid(q k) v folded into the gated stencil
-_FANOUT = _os.environ.get("KMU_FANOUT", "1") == "1"          # multi-consumer tensors: one gradient fan-in launch (ops.fanout)
-_MEAN_QKV = _os.environ.get("KMU_MEAN_QKV", "1") == "1"      # DirectionAttention: pool + qkv projection as one autograd node
-_PYR_STREAMS = int(_os.environ.get("KMU_PYR_STREAMS", "2"))      # 2: one stream per pyramid, 1: both on one, 0: on the main stream
 
 
 def _pyramid_streams(device):
     key = (device.type, device.index)
     if key not in _PYR:
         a = torch.cuda.Stream(device=device)
-        _PYR[key] = (a, torch.cuda.Stream(device=device) if _PYR_STREAMS >= 2 else a)
+        _PYR[key] = (a, torch.cuda.Stream(device=device))
     return _PYR[key]
 
 
@@ -151,13 +146,13 @@ class DirectionAttention(nn.Module):
 
     def forward(self, x):
         b, c = x.shape[:2]
-        if x.is_cuda and not _TORCH_GLUE and _MEAN_QKV and ops.pwconv_supported(c, 3 * c, x.shape[2] * x.shape[3]):
+        if x.is_cuda and not _TORCH_GLUE and ops.pwconv_supported(c, 3 * c, x.shape[2] * x.shape[3]):
             pooled, qkv = ops.mean_pwconv(x, self.qkv.weight, self.qkv.bias)      # one node: no fan-in add in the backward
             gate = gate_mlp(pooled, self.fc[0], self.fc[2], "gelu")
         else:
             gate = gate_mlp(_spatial_mean(x), self.fc[0], self.fc[2], "gelu")
             qkv = conv1x1(x, self.qkv)
-        if _QKV_DW and x.is_cuda and not _TORCH_GLUE and ops.qkv_gate_dw_supported(b, c, qkv.shape[2], qkv.shape[3]):
+        if x.is_cuda and not _TORCH_GLUE and ops.qkv_gate_dw_supported(b, c, qkv.shape[2], qkv.shape[3]):
             # sigmoid(q*k)*v formed inside the gated stencil, forward and backward: attn is never stored
             return ops.qkv_gate_dw(qkv, self.conv.weight, self.conv.bias, gate)
         if (qkv.shape[2] * qkv.shape[3]) % 4 == 0 and "qkv_gate" not in _TORCH_GLUE:
@@ -237,7 +232,7 @@ class EnhancedViMBlock(nn.Module):
         64x64 / 32x32 levels are far too small to fill 256 CUs one at a time.  xw / xc: aliases of x for the width / channel
         branch (ops.fanout: one gradient fan-in launch instead of pairwise adds)."""
         xw, xc = (x if xw is None else xw), (x if xc is None else xc)
-        if not (x.is_cuda and _BRANCH_STREAMS and x.shape[1] >= _BRANCH_MIN_C):
+        if not (x.is_cuda and _BRANCH_STREAMS):
             return [self.height_block(x), self.width_block(xw), self.channel_block(xc)]
         cur = torch.cuda.current_stream()
         side = _side_streams(x.device)
@@ -264,7 +259,7 @@ class EnhancedViMBlock(nn.Module):
             x = grouped.GatedMix3StackedFn.apply(x, F3, fg[1].weight, fg[1].bias, fg[3].weight, fg[3].bias,
                                                  dp.scale(x) if dp is not None else None)
             return self._ffn(x, dp)
-        if x.is_cuda and _FANOUT and not _TORCH_GLUE:
+        if x.is_cuda and not _TORCH_GLUE:
             x, xh, xw, xc = ops.fanout(x, 4)      # residual + three branches: their four gradients meet in one launch
             feats = self._branches(xh, xw, xc)
         else:
@@ -396,7 +391,7 @@ class KM_UNetV3(nn.Module):
         self._mask_pool.reset()
         x = conv3x3(x.float(), self.conv_f)
         e1 = self.lca1(self.enc1(x))
-        fan = x.is_cuda and _FANOUT and not _TORCH_GLUE
+        fan = x.is_cuda and not _TORCH_GLUE
         # e1 / e2 feed the next encoder stage and both pyramids: aliases whose three gradients meet in one launch (ops.fanout)
         e1, *e1p = ops.fanout(e1, 3) if fan else (e1, e1, e1)
         e2 = self.lca2(self.enc2(e1))
@@ -407,7 +402,7 @@ class KM_UNetV3(nn.Module):
         # autograd replays their backward on the same streams, beside the decoder's.
         h2, w2 = e2.shape[2:]
         pyr = [None, None]
-        if x.is_cuda and _BRANCH_STREAMS and _PYR_STREAMS > 0 and h2 % 2 == 0 and w2 % 2 == 0:
+        if x.is_cuda and _BRANCH_STREAMS and h2 % 2 == 0 and w2 % 2 == 0:
             cur = torch.cuda.current_stream()
             ready = cur.record_event()
             for i, (st, att, size) in enumerate(zip(_pyramid_streams(x.device), (self.attention1, self.attention2),

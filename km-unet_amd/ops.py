@@ -82,17 +82,8 @@ def _ptr(t):
 # captured graph (16.9 vs 15.05 ms/step): every cross-stream edge costs the main chain more than the ~5 us leaf it moves.
 # Off by default: a bare `.backward()` followed by a read of `.grad` must see finished gradients.
 WGRAD_OVERLAP = False
-WGRAD_BATCH = int(os.environ.get("KMU_WGRAD_BATCH", "4096"))
-WGRAD_STREAMS = int(os.environ.get("KMU_WGRAD_STREAMS", "4"))      # 3 vs 4 vs 5: within the box-to-box noise (+-0.07 ms)
-# dense-conv weight gradients started where autograd reaches them instead of in the tail: all 16 of them neutral (10.17 / 10.22 vs
-# 10.18 / 10.09 ms/step), only the decoder's first 4 (KMU_WGRAD_EARLY_N) WORSE (9.61 / 9.58 / 9.61 / 9.62 vs 9.43 / 9.53 / 9.44 / 9.45,
-# four interleaved pairs): a 100 us kernel beside the activation-gradient chain slows the chain's own kernels by more than the tail
-# gets shorter; off by default
-WGRAD_EARLY = os.environ.get("KMU_WGRAD_EARLY", "0") == "1"
-WGRAD_EARLY_N = int(os.environ.get("KMU_WGRAD_EARLY_N", "1000"))    # only the first N dense-conv jobs of a backward pass (the decoder's) go early
-_WG_EARLY = {}
-_WG_EARLY_KEEP = []
-WGRAD_GROUP = os.environ.get("KMU_WGRAD_GROUP", "1") == "1"     # identical pointwise-conv weight gradients share a launch
+WGRAD_BATCH = 4096      # jobs per mid-backward flush: larger than a step's queue -- one flush at the end measured best (32..512: +0.5 ms)
+WGRAD_STREAMS = 4       # side lanes of the flush (3 / 4 / 5 within +-0.07 ms)
 _WG_SIDE = {}
 _WG_JOBS = []
 _WG_BUSY = set()
@@ -114,21 +105,6 @@ def _leaf(*ts):
 def _wgrad(job, defer=True, heavy=False):
     if not (WGRAD_OVERLAP and defer):
         job()
-        return
-    if heavy and WGRAD_EARLY and len(_WG_EARLY_KEEP) < WGRAD_EARLY_N:
-        # the dense KxK / KAN weight gradients (16 jobs of 30-110 us, ~1 ms per step) are long enough to pay for a cross-stream
-        # edge each: they start at once on a stream of their own, beside the activation-gradient chain, instead of in the tail.
-        # The closure (holding x and dy) is kept until the final join: the producers' allocator must not recycle their blocks
-        # while the side stream still reads them.
-        cur = torch.cuda.current_stream()
-        early = _WG_EARLY.get(cur.device.index)
-        if early is None:
-            early = _WG_EARLY[cur.device.index] = torch.cuda.Stream(device=cur.device)
-        early.wait_event(cur.record_event())
-        with torch.cuda.stream(early):
-            job()
-        _WG_BUSY.add(early)
-        _WG_EARLY_KEEP.append(job)
         return
     _WG_JOBS.append((torch.cuda.current_stream(), job))
     if len(_WG_JOBS) >= WGRAD_BATCH:
@@ -168,7 +144,6 @@ def flush_wgrad_jobs(final=True):
         for side in _WG_BUSY:
             cur.wait_stream(side)
         _WG_BUSY.clear()
-        _WG_EARLY_KEEP.clear()
         if batch:
             _issue_batched(batch)       # on the joining stream, behind every job's first stage
 
@@ -263,12 +238,7 @@ def _pw_wgrad_call(lib, x, gy, dw, db, B, ci, co, P, act_in):
         return
     # only registered: problems of identical dimensions (the same layer of the three branches / the two blocks of a level) share a
     # launch (_issue_pw_partials), and every slab reduction shares one (_issue_batched)
-    if WGRAD_GROUP:
-        _WG_BATCH["pw"].append((x, gy, ws, dw, db, B, ci, co, P, int(act_in)))
-    else:
-        _lib.check(_call(("pwconv_bwd_weight", (B, ci, co, P)), lib.kmu_pwconv_bwd_weight_partial, _ptr(x), _ptr(gy), _ptr(ws), nbytes,
-                         int(db is not None), B, ci, co, P, int(act_in), _stream()), "kmu_pwconv_bwd_weight_partial")
-        _WG_BATCH["pwred"].append((ws, dw, db, B, ci, co, P))
+    _WG_BATCH["pw"].append((x, gy, ws, dw, db, B, ci, co, P, int(act_in)))
 
 
 def _issue_pw_partials(batch, lanes):
@@ -346,7 +316,6 @@ def _issue_batched(batch):
 # forward's); from the second step on `prepack()` refills ALL known packs with two launches (one job table per source file:
 # kmu_conv_pack_multi, kmu_hsm_pack_multi) at the head of the step, so a captured hipGraph starts with them and every replay
 # re-packs the current weights.  Outside a scope nothing is cached: a bare forward always packs the weights it is given.
-PACK_ONCE = os.environ.get("KMU_PACK_ONCE", "1") == "1"
 
 
 class PackCache:
@@ -394,7 +363,7 @@ class pack_scope:
 
     def __enter__(self):
         self.outer = _PACKS.enabled
-        if not self.outer and PACK_ONCE:
+        if not self.outer:
             _PACKS.enabled = True
             _PACKS.epoch += 1
         return self
@@ -1952,10 +1921,10 @@ class FfnBlendFn(torch.autograd.Function):
 
 # The FFN stage as recompute kernels (csrc/ffn_fused.hip): nothing 4C wide is stored.  KMU_FFN_FUSED=0 keeps the pointwise-conv +
 # BatchNorm kernels (FfnBlendFn), which also serve the shapes the fused kernels do not cover (C not in {16, 32, 64}, H*W % 64 != 0).
-FFN_FUSED = os.environ.get("KMU_FFN_FUSED", "1") == "1"
-TAIL_FUSED = os.environ.get("KMU_TAIL_FUSED", "1") == "1"      # EnhancedViMBlock's tail FFN as one recompute launch each way
-DWBN_FUSED = os.environ.get("KMU_DWBN_FUSED", "1") == "1"      # dwconv stage backward: BatchNorm folded into the transposed stencil
-DWBN_ALL = os.environ.get("KMU_DWBN_ALL", "1") == "1"          # ... and the weight-gradient taps taken in the same launch
+FFN_FUSED = True
+TAIL_FUSED = True     # EnhancedViMBlock's tail FFN as one recompute launch each way
+DWBN_FUSED = True     # dwconv stage backward: BatchNorm folded into the transposed stencil
+DWBN_ALL = True       # ... and the weight-gradient taps taken in the same launch
 _FFN_STAGES_F = ("ffn_fwd_stats", "ffn_fwd_main", "ffn_fwd_apply")
 _FFN_STAGES_B = ("ffn_bwd_red", "ffn_bwd_mid", "ffn_bwd_in")
 

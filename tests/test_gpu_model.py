@@ -522,3 +522,38 @@ def test_graphed_step_refuses_too_few_hw_queues():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "REFUSED True" in r.stdout, (r.stdout, r.stderr[-1000:])
+
+
+@pytest.mark.parametrize("names", ["conv1x1,pwconv,conv3x3,conv3tap", "gate_mlp,group_norm,layer_norm,mix3,qkv_gate",
+                                   "dwconv,bn_blend,evim_composite", "dagem,iwp,resize"])
+def test_torch_glue_twins_match_hip_glue(names):
+    """KMU_GLUE_TORCH=<names> swaps the named glue kernels for their stock-PyTorch twins (a numerics-bisection aid: nn.py:18).  The
+    twins are product code paths too -- they also serve shapes the glue kernels do not take -- so each group is run once against the
+    default kernels on the small SH model in train mode: same output (1e-4) and input gradient (relative L2 1e-3; a ReLU tie may
+    move single entries)."""
+    import km_unet_amd.nn as NN
+    m = _build("SH", 5, True)
+    gen = torch.Generator().manual_seed(11)
+    x0 = torch.rand(2, 5, 32, 32, generator=gen).cuda()
+    tgt = torch.rand(2, 5, 32, 32, generator=gen).cuda()
+
+    def run():
+        for mod in m.modules():                     # same BatchNorm state for both runs
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.reset_running_stats()
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        torch.nn.functional.mse_loss(y, tgt).backward()
+        return y.detach(), x.grad.detach()
+
+    y0, dx0 = run()
+    saved = set(NN._TORCH_GLUE)
+    NN._TORCH_GLUE.update(names.split(","))         # model.py holds the same set object
+    try:
+        y1, dx1 = run()
+    finally:
+        NN._TORCH_GLUE.clear()
+        NN._TORCH_GLUE.update(saved)
+    e_y, e_dx = rel_err(y1, y0), rel_l2(dx1, dx0)
+    print("  [glue twins %s] y=%.2e dx(L2)=%.2e" % (names, e_y, e_dx))
+    assert e_y < 1e-4 and e_dx < 1e-3

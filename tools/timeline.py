@@ -24,7 +24,12 @@ def main():
     with open(path, newline="") as f:
         rd = csv.DictReader(f)
         cols = rd.fieldnames
-        pick = lambda *keys: next(c for c in cols if all(k.lower() in c.lower() for k in keys))
+        def pick(*keys):
+            for c in cols:
+                if all(k.lower() in c.lower() for k in keys):
+                    return c
+            raise SystemExit("timeline.py: %s has no column matching %s (columns: %s) -- expected a rocprofv3 --kernel-trace CSV"
+                             % (sys.argv[1], "+".join(keys), ", ".join(cols)))
         c_name, c_s, c_e, c_q = pick("kernel", "name"), pick("start"), pick("end"), pick("queue")
         for r in rd:
             nm = r[c_name]
@@ -52,8 +57,6 @@ def main():
     for s, e, q, n in ev:
         if s > cur_end:
             idle_windows.append((s - cur_end, n, cur_end - t0))
-            busy += 0
-            cur_start = s
         if e > cur_end:
             busy += e - max(s, cur_end)
             cur_end = e
