@@ -27,6 +27,7 @@ instrumented steps (ms per step, GB/s, TFLOP/s for ~200 (kernel, shape) pairs) g
 import argparse
 import json
 import os
+import re
 import sys
 import time
 import warnings
@@ -81,9 +82,12 @@ def kernel_model(name, shape):
 def _kernel_model(name, shape):
     # entry-point suffixes name the arithmetic / calling form, not the work: _x3 (split-bf16 matrix core), _v2 (round-4 forward),
     # _g (grouped: the shape's B already counts samples x groups), _pk (pack handed in)
-    base = name
-    for suf in ("_pk", "_g", "_x3", "_v2"):
-        base = base.replace(suf, "")
+    base, again = name, True
+    while again:
+        again = False
+        for suf in ("_pk", "_g", "_x3", "_v2"):
+            if base.endswith(suf):
+                base, again = base[:-len(suf)], True
     if base.startswith("kan_conv2d"):
         B, Cin, Cout, H, W = shape
         flops = 2.0 * B * H * W * (81 * Cin) * Cout           # implicit GEMM, K = 9 taps x 9 basis x Cin
@@ -97,7 +101,7 @@ def _kernel_model(name, shape):
         B, C, Hs = shape
         L, N = Hs * Hs, 64
         proj, dw, mix = 2.0 * N * C, 2.0 * 9 * N, 2.0 * C * N       # per token, per group of N rows of BCdt
-        v2 = name.endswith("_v2") or "_v2_" in name
+        v2 = "_v2" in name
         # tensors = algorithmic [B,C,L] reads + writes.  v2 pass 2 is the per-sample dense 3x3 (9 C^2 MACs per token) and also writes the
         # normalised x for the backward pass
         per_token = {"fwd_pass1": (2 * proj + 2 * dw + mix, 1), "fwd_pass2": ((2.0 * 9 * C * C, 3) if v2 else (proj + dw + mix, 2)),
@@ -180,6 +184,33 @@ def _kernel_model(name, shape):
     if name.startswith("gauss11"):
         N, H, W = shape
         return "hbm", 2.0 * 22 * N * H * W, t * N * H * W * 2
+    m = re.match(r"conv(\d)x\d_(fwd|dgrad|bwd_weight)", base)
+    if m:                                         # plain K x K convolutions on the bf16 matrix core: [B, Cin, Cout, H, W]
+        B, Cin, Cout, H, W = shape
+        K = int(m.group(1))
+        flops = 2.0 * B * H * W * K * K * Cin * Cout
+        return "mfma", flops, t * (B * H * W * (Cin + Cout) + K * K * Cin * Cout)
+    if base.startswith("add_n"):
+        n, numel = shape
+        return "hbm", 0.0, t * numel * (n + 1)
+    if base.startswith("relu_mask"):
+        return "hbm", 0.0, t * shape[0] * 3
+    if base.startswith(("colsum_multi", "bias_sum_multi", "copy_multi")):     # shape = element counts of the partial arrays / jobs
+        return "hbm", 0.0, t * max(1, sum(shape)) * (2 if base.startswith("copy") else 1)
+    if base.startswith("deform_sample"):
+        B, C, H, W = shape
+        return "hbm", 0.0, t * B * H * W * (C + 18 + 9 * C) * (2 if base.endswith("bwd") else 1)
+    if base.startswith("gate_mlp"):               # pooled vectors through a two-layer MLP: a few KB
+        B, I, Hd, O = shape
+        return "hbm", 2.0 * B * (I * Hd + Hd * O), t * (B * (I + O) + I * Hd + Hd * O)
+    if base.startswith(("conv_pack_multi", "hsm_pack_multi")):                # weight re-layouts: all packed weights once (~2 x 1.7 M params)
+        return "hbm", 0.0, t * 1.7e6 * 2
+    if base.startswith("hybrid_loss"):
+        N, H, W = shape
+        return "hbm", 0.0, t * N * H * W * {"stats": 2, "stack": 7, "combine": 5, "grad_maps": 8, "grad_input": 8}.get(base.split("hybrid_loss_")[1], 4)
+    if base.startswith("resize_bilinear"):
+        B, C, Hi, Wi, Ho, Wo = shape
+        return "hbm", 0.0, t * B * C * (Hi * Wi + Ho * Wo)
     return "hbm", 0.0, 0.0
 
 

@@ -194,3 +194,26 @@ def test_cosine_annealing_matches_torch_scheduler():
         mine.step()
         assert abs(ref.get_last_lr()[0] - mine.get_last_lr()[0]) < 1e-9, epoch
     assert opt.param_groups[0]["lr"] is lr_t            # same tensor object, updated in place
+
+
+def test_bench_kernel_model_covers_every_recorded_entry_point():
+    """bench.py's per-entry-point table divides algorithmic bytes / FLOP by the measured launch time; a key the model does not know
+    reports 0 GB/s (round 3: the suffixed K2 names fell through to a default).  tests/golden/bench_kernel_keys.json = the (entry point,
+    shape) keys of one full bench run (gpurun_out/bench_kernels.json, round 4): every one must get a non-zero byte count."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("kmu_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    keys = json.load(open(os.path.join(GOLDEN, "bench_kernel_keys.json")))
+    assert len(keys) > 250
+    missing = []
+    for k in keys:
+        name, shp = k.split("[", 1)
+        bound, flops, byts = b.kernel_model(name, json.loads("[" + shp))
+        if not byts > 0:
+            missing.append(k)
+    assert not missing, missing[:10]
+    # the round-4 names resolve to their own models
+    assert b.kernel_model("hsmssd_fwd_pass1_v2", [8, 16, 128])[2] == 4.0 * 8 * 16 * 128 * 128
+    assert b.kernel_model("hsmssd_bwd_passB_g", [24, 64, 32])[1] > 0

@@ -30,6 +30,17 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
 torch.cuda.synchronize()
 print("done")
 
+# ---- round 4: LayerNorm1D + HSMSSD forward as the two launches of csrc/hsmssd_v2.inc at the three level shapes of the bench
+for (Bm, Cm, Hm) in ((8, 16, 128), (8, 32, 64), (24, 64, 32)):
+    xm = torch.randn(Bm, Cm, Hm * Hm, device=d, requires_grad=True)
+    lw, lb = torch.ones(Cm, device=d, requires_grad=True), torch.zeros(Cm, device=d, requires_grad=True)
+    wm = [torch.randn(3 * N, Cm, 1, device=d) / Cm ** 0.5, torch.randn(3 * N, 1, 3, 3, device=d) * 0.3, torch.randn(2 * Cm, Cm, 1, device=d) / Cm ** 0.5,
+          torch.randn(Cm, Cm, 1, device=d) / Cm ** 0.5, torch.ones(N, device=d), torch.ones(1, device=d)]
+    for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+        ym, hm = ops.mixer_ln(xm, lw, lb, 1e-5, *wm)
+torch.cuda.synchronize()
+print("mixer done")
+
 # ---- streaming glue kernels at the bench shapes (for the FETCH_SIZE / WRITE_SIZE passes) --------------------------
 import torch.nn as nn
 xg = torch.randn(B, 16, 128, 128, device=d, requires_grad=True)
