@@ -55,15 +55,16 @@ RIDGE = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # FLOP/B at which f
 
 
 def pmc_traffic(name, shape):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03c_pmc_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r04a_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), measured at the bench shape only; None for
     kernels / shapes without a PMC pass."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r03c_pmc_traffic.json")))["kernels"]
+        table = json.load(open(os.path.join(ROOT, "profiles", "r04a_pmc_traffic.json")))["kernels"]
     except Exception:
         return None
     key = {("hsmssd_bwd_passB", (8, 16, 128)): "hsm_bwd_passB<16>", ("hsmssd_bwd_passA_x3", (8, 16, 128)): "hsm_bwd_passA_x3<16>",
-           ("hsmssd_fwd_pass2_x3", (8, 16, 128)): "hsm_fwd_pass2_x3<16>",
+           ("hsmssd_fwd_pass1_v2", (8, 16, 128)): "hsm2_fwd_pass1<16, 4, 8, true>", ("hsmssd_fwd_pass2_v2", (8, 16, 128)): "hsm2_fwd_pass2<16>",
+           ("hsmssd_fwd_pass1_v2", (8, 32, 64)): "hsm2_fwd_pass1<32, 1, 8, false>", ("hsmssd_fwd_pass2_v2", (8, 32, 64)): "hsm2_fwd_pass2<32>",
            ("kan_conv2d_fwd_x3", (8, 16, 16, 128, 128)): "conv3x3_x3_fwd_kernel<0, 3, 8, 32, 4, 1, 1>",
            ("kan_conv2d_bwd_input_x3", (8, 16, 16, 128, 128)): "kan_dgrad_x3_kernel<4, 32>",
            ("pwconv_fwd", (8, 16, 64, 16384)): "pw_gemm_kernel<4>"}.get((name, tuple(shape)))
@@ -457,8 +458,10 @@ def main():
         (name, shape) = next(k for k in prof if "%s%s" % (k[0], list(k[1])) == dom)
         bound, flops, byts = kernel_model(name, shape)
         if bound == "mfma":
+            # `frac` is against the roof of the instruction the kernel issues (exact-fp32 MFMA, 157.3 TF); every other contraction of
+            # the step runs split-bf16 on the bf16 matrix core (2.5 PF / 3 products = 833 TF effective): that fraction beside it
             roof = {"bound": "mfma", "achieved": d["TFLOP/s"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": d["TFLOP/s"] / PEAK_F32_MFMA_TFLOPS}
+                    "frac": d["TFLOP/s"] / PEAK_F32_MFMA_TFLOPS, "frac_bf16x3_roof": d["TFLOP/s"] / (2500.0 / 3.0)}
         else:
             roof = {"bound": "hbm", "achieved": d["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["GB/s"] / PEAK_HBM_GBS}
         roof.update({"traffic": pmc_traffic(name, shape), "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_flops": flops,
