@@ -616,8 +616,9 @@ int kmu_hsm_pack_multi(const void* device_table, int njobs, kmu_stream_t stream)
  *            sample's tiles in tile order, applies hz_proj / SiLU gate / out_proj (:52-55), writes `state` (layout of
  *            kmu_hsmssd_fwd: [M | S | hpre | hz | h2], read by kmu_hsmssd_bwd*), h, and the per-sample dense 3x3 weights
  *            M_b = h2 . Wc of stage 1 into ws.  No workgroup waits for another one.
- *   stage 1  pass 2: y = conv3x3(LayerNorm(x); M_b)  (== h2 . Cm, :57-59); optional outputs xn [B,C,L] (the normalised x: the
- *            `x` operand of kmu_hsmssd_bwd*) and rstd_mean [B,L,2] (kmu_layernorm1d_bwd*).
+ *   stage 1  pass 2: y = conv3x3(LayerNorm(x); M_b)  (== h2 . Cm, :57-59); optional outputs rstd_mean [B,L,2] (kmu_layernorm1d_bwd*,
+ *            kmu_mixer_bwd_stage) and xn [B,C,L] (the normalised x: the `x` operand of kmu_hsmssd_bwd*; not needed with
+ *            kmu_mixer_bwd_stage, which re-derives it on load).
  * ln_weight / ln_bias [groups, C] (both NULL: no LayerNorm, x is the mixer input itself, xn / rstd_mean must be NULL).
  * wpk: kmu_hsmssd_pack_x3 / kmu_hsm_pack_multi output (kmu_hsmssd_pack_elems elements).  groups as kmu_hsmssd_*_g.
  * tickets: B zero-initialised 32-bit words in device memory that no other in-flight launch uses; the kernel leaves them zero.
@@ -627,6 +628,14 @@ int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const float* ln_
                         const float* w_out, const float* D, const void* wpk, float* y, float* h, float* state, float* xn,
                         float* rstd_mean, void* ws, size_t ws_bytes, unsigned int* tickets, int B, int C, int N, int Hs, int stage,
                         int groups, kmu_stream_t stream);
+/* The K2 backward stages (kmu_hsmssd_bwd_stage_x3_pk: 0 = pass A, 1 = gate, 2 = pass B) with LayerNorm1D applied on load: x is the block's
+ * input, rstd_mean [B,L,2] the statistics kmu_mixer_fwd_stage left, ln_weight / ln_bias [groups, C]; dx = gradient with respect to the
+ * NORMALISED x (hand it to kmu_layernorm1d_bwd_add with x and rstd_mean).  The forward then need not store the normalised tensor. */
+int kmu_mixer_bwd_stage(const float* x, const float* ln_weight, const float* ln_bias, const float* rstd_mean, const float* dy, const float* dh,
+                        const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out, const float* D, const float* state,
+                        float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
+                        float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, const void* wpk,
+                        kmu_stream_t stream);
 void kmu_mixer_debug_rows(int rows); /* tools only: force pass 1's configuration (H | 16: 8 waves | 32: wide tiles; 0 = automatic) */
 void kmu_conv_debug_split(int mode); /* tools only: K1 / KxK forward at small images: 0 automatic, 1 never split Cout tiles over workgroups, 2 always */
 

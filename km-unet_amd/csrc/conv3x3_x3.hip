@@ -927,7 +927,7 @@ extern "C" int kmu_conv_pack_job(void* table, int index, int which, const float*
 
 extern "C" int kmu_conv_pack_multi(const void* device_table, int njobs, kmu_stream_t stream) {
     KMU_REQUIRE(device_table && njobs > 0 && njobs <= 65535, "conv_pack_multi: bad arguments");
-    hipLaunchKernelGGL(conv_pack_multi_kernel, dim3(24, njobs), dim3(256), 0, (hipStream_t)stream, (const ConvPackJob*)device_table);
+    hipLaunchKernelGGL(conv_pack_multi_kernel, dim3(96, njobs), dim3(256), 0, (hipStream_t)stream, (const ConvPackJob*)device_table);
     return kmu::launch_status("conv_pack_multi");
 }
 

@@ -702,7 +702,7 @@ template <int C>
 int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
                 const float* w_out, const float* D, const float* state, float* dx, float* p_bcdt, float* p_dw, float* p_hz,
                 float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st, int NG = 1,
-                const void* wpk_ext = nullptr) {
+                const void* wpk_ext = nullptr, const float* ln_stats = nullptr, const float* ln_w = nullptr, const float* ln_b = nullptr) {
     int txA;
     const int TA = tiles_x3<C>(Hs, &txA);
     float* partA = ws;
@@ -720,7 +720,8 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
             if (rc) return rc;
         }
         KMU_MAX_LDS(hsm_bwd_passA_x3<C>, la);
-        hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA, NG);
+        hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA, NG,
+                           ln_stats, ln_w, ln_b);
         rc = kmu::launch_status("hsmssd_bwd passA (bf16x3)");
         if (rc) return rc;
     }
@@ -737,7 +738,7 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
             const size_t lbf = lds_passB<C>();
             KMU_MAX_LDS(hsm_bwd_passB<C>, lbf);
             hipLaunchKernelGGL(hsm_bwd_passB<C>, dim3(TBF, B, passB_split(C, Hs)), dim3(TileForB<C>::NW * 64), lbf, st, x, dy, w_bcdt, w_dw,
-                               state, dhp, delta, dx, p_bcdt, p_dw, Hs, txF, NG);
+                               state, dhp, delta, dx, p_bcdt, p_dw, Hs, txF, NG, ln_stats, ln_w, ln_b);
             rc = kmu::launch_status("hsmssd_bwd passB");
         }
     }
@@ -902,9 +903,11 @@ static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, c
                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
-                             int Hs, int stages, kmu_stream_t stream, bool x3 = false, int groups = 1, const void* wpk = nullptr) {
+                             int Hs, int stages, kmu_stream_t stream, bool x3 = false, int groups = 1, const void* wpk = nullptr,
+                             const float* ln_stats = nullptr, const float* ln_w = nullptr, const float* ln_b = nullptr) {
     KMU_REQUIRE(groups >= 1 && (groups == 1 || x3) && B % groups == 0, "hsmssd_bwd: %d weight groups need the bf16x3 path and B %% groups == 0",
                 groups);
+    KMU_REQUIRE(!ln_stats || (x3 && ln_w && ln_b), "hsmssd_bwd: LayerNorm on load needs the bf16x3 path and both affine parameters");
     KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial &&
                     d_w_hz_partial && d_w_out_partial && d_D_partial && ws,
                 "hsmssd_bwd: null pointer");
@@ -919,12 +922,12 @@ static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, c
     if (x3) {
         if (C == 16)
             return bwd_impl_x3<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk, ln_stats, ln_w, ln_b);
         if (C == 32)
             return bwd_impl_x3<32>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk, ln_stats, ln_w, ln_b);
         return bwd_impl_x3<64>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
+                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk, ln_stats, ln_w, ln_b);
     }
     if (C == 16)
         return bwd_impl<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
@@ -1002,7 +1005,7 @@ extern "C" int kmu_hsm_pack_job(void* table, int index, const float* w_bcdt, con
 
 extern "C" int kmu_hsm_pack_multi(const void* device_table, int njobs, kmu_stream_t stream) {
     KMU_REQUIRE(device_table && njobs > 0 && njobs <= 65535, "hsm_pack_multi: bad arguments");
-    hipLaunchKernelGGL(hsm_pack_multi_kernel, dim3(12, njobs), dim3(256), 0, (hipStream_t)stream, (const HsmPackJob*)device_table);
+    hipLaunchKernelGGL(hsm_pack_multi_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)stream, (const HsmPackJob*)device_table);
     return kmu::launch_status("hsm_pack_multi");
 }
 
@@ -1025,6 +1028,21 @@ extern "C" int kmu_hsmssd_bwd_stage_x3_pk(const float* x, const float* dy, const
                              d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups, wpk);
 }
 
+// kmu_hsmssd_bwd_stage_x3_pk with LayerNorm1D applied on load: x is the block's input (NOT normalised), rstd_mean [B,L,2] the forward's
+// statistics (kmu_mixer_fwd_stage), ln_weight / ln_bias [groups, C].  dx is the gradient with respect to the NORMALISED x (feed it to
+// kmu_layernorm1d_bwd_add together with x and rstd_mean).
+extern "C" int kmu_mixer_bwd_stage(const float* x, const float* ln_weight, const float* ln_bias, const float* rstd_mean, const float* dy,
+                                   const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
+                                   const float* D, const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
+                                   float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B,
+                                   int C, int N, int Hs, int stage, int groups, const void* wpk, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 2, "mixer_bwd_stage: stage must be 0 (pass A), 1 (gate) or 2 (pass B)");
+    KMU_REQUIRE(ln_weight && ln_bias && rstd_mean && wpk, "mixer_bwd_stage: null pointer");
+    return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial, d_w_hz_partial,
+                             d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups, wpk, rstd_mean,
+                             ln_weight, ln_bias);
+}
+
 // ---- round 4: LayerNorm1D + HSMSSD forward in two launches (csrc/hsmssd_v2.inc) ---------------------------------------------
 extern "C" size_t kmu_mixer_fwd_ws_bytes(int B, int C, int N, int Hs) {
     (void)N;
@@ -1037,7 +1055,7 @@ extern "C" int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const
                                    int Hs, int stage, int groups, kmu_stream_t stream) {
     KMU_REQUIRE(x && w_dw && w_hz && w_out && D && wpk && y && h && state && ws && tickets, "mixer_fwd: null pointer");
     KMU_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "mixer_fwd: LayerNorm weight and bias come together (both NULL: x is used as it is)");
-    KMU_REQUIRE(!ln_weight || ((xn == nullptr) == (rstd_mean == nullptr)), "mixer_fwd: xn and rstd_mean come together");
+    KMU_REQUIRE(!xn || rstd_mean, "mixer_fwd: xn comes with rstd_mean");
     KMU_REQUIRE(ln_weight || (!xn && !rstd_mean), "mixer_fwd: xn / rstd_mean are outputs of the LayerNorm prologue only");
     KMU_REQUIRE(N == NS, "mixer_fwd: state_dim=%d unsupported (kernels are built for 64)", N);
     KMU_REQUIRE(C == 16 || C == 32 || C == 64, "mixer_fwd: C=%d unsupported (16/32/64)", C);

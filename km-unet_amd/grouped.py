@@ -184,7 +184,7 @@ class HsmssdGFn(torch.autograd.Function):
 class MixerGFn(torch.autograd.Function):
     """(y [B*G, C, Hs, Hs], x') = HSMSSD(LayerNorm1D(x [B*G, C, L])) with G weight sets (sample b: set b % G), the two launches of
     csrc/hsmssd_v2.inc (ops.MixerFn, grouped); x' aliases x for the blend that follows: its gradient is added inside the LayerNorm
-    backward kernel.  Backward = the grouped bf16x3 HSMSSD backward + the grouped LayerNorm backward."""
+    backward kernel.  Backward = the grouped bf16x3 HSMSSD backward (LayerNorm re-applied on load: kmu_mixer_bwd_stage) + the grouped LayerNorm backward."""
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, eps, w_bcdt, w_dw, w_hz, w_out, A, D):
@@ -206,8 +206,7 @@ class MixerGFn(torch.autograd.Function):
         lw, lb = _f32c(ln_w, "norm.weight").reshape(-1), _f32c(ln_b, "norm.bias").reshape(-1)
         dev = x.device
         need_bwd = any(ctx.needs_input_grad)
-        xn = torch.empty_like(x) if need_bwd else None
-        stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32) if need_bwd else None
+        stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32) if need_bwd else None     # the backward re-derives LayerNorm(x) on load
         y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
         h = torch.empty(B, C, N, device=dev, dtype=torch.float32)
         state = torch.empty(lib.kmu_hsmssd_state_elems(B, C, N), device=dev, dtype=torch.float32)
@@ -218,9 +217,9 @@ class MixerGFn(torch.autograd.Function):
         tk = ops._tickets(dev, B)
         for stage, nm in enumerate(("hsmssd_fwd_pass1_v2", "hsmssd_fwd_pass2_v2")):
             _lib.check(_call((nm + "_g", (B, C, Hs)), lib.kmu_mixer_fwd_stage, _ptr(x), _ptr(lw), _ptr(lb), float(eps), _ptr(w_dw), _ptr(w_hz),
-                             _ptr(w_out), _ptr(D), _ptr(wpk), _ptr(y), _ptr(h), _ptr(state), _ptr(xn), _ptr(stats), _ptr(ws), nbytes,
+                             _ptr(w_out), _ptr(D), _ptr(wpk), _ptr(y), _ptr(h), _ptr(state), None, _ptr(stats), _ptr(ws), nbytes,
                              _ptr(tk), B, C, N, Hs, stage, G, st), "kmu_mixer_fwd_stage")
-        ctx.save_for_backward(x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state)
+        ctx.save_for_backward(x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state)
         ctx.set_materialize_grads(False)
         ctx.dims = (B, C, N, Hs)
         ctx.zero_A = ops._const_zeros(A)
@@ -230,7 +229,7 @@ class MixerGFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dalias):
         lib = _lib.load()
-        x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+        x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
         B, C, N, Hs = ctx.dims
         L = Hs * Hs
         dev = x.device
@@ -250,9 +249,9 @@ class MixerGFn(torch.autograd.Function):
         st = _stream()
         wpk = ops._hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st, G)
         for stage, nm in enumerate(("hsmssd_bwd_passA_x3", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):
-            _lib.check(_call((nm + "_g", (B, C, Hs)), lib.kmu_hsmssd_bwd_stage_x3_pk, _ptr(xn), _ptr(dy), None, _ptr(w_bcdt), _ptr(w_dw),
-                             _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dxn), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz), _ptr(p_out),
-                             _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, G, _ptr(wpk), st), "kmu_hsmssd_bwd_stage_x3_pk")
+            _lib.check(_call((nm + "_g", (B, C, Hs)), lib.kmu_mixer_bwd_stage, _ptr(x), _ptr(lw), _ptr(lb), _ptr(stats), _ptr(dy), None,
+                             _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dxn), _ptr(p_bcdt), _ptr(p_dw),
+                             _ptr(p_hz), _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, G, _ptr(wpk), st), "kmu_mixer_bwd_stage")
         mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         d_bcdt, d_dw, d_hz, d_out, d_D = mk(G, 3 * N * C), mk(G, 3 * N * 9), mk(G, 2 * C * C), mk(G, C * C), mk(G)
         Bs, tb, gp = B // G, P // B, Gp // B    # partial rows are (sample b, tile / gate block): the group of a row is b % G

@@ -721,9 +721,11 @@ def _hsm_pack(ok, w_bcdt, w_dw, C, st, groups=1):
                    lambda buf: _lib.check(lib.kmu_hsmssd_pack_x3(_ptr(w_bcdt), _ptr(w_dw), _ptr(buf), C, groups, st), "kmu_hsmssd_pack_x3"))
 
 
-def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, defer):
+def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, defer, ln=None):
     """Backward of HSMSSD.forward given the (normalised) input x, the saved gate state and dy / dh: three launches (pass A, gate,
-    pass B) + the deferred column sums of the parameter-gradient partials.  -> dx, (d_bcdt, d_dw, d_hz, d_out, d_D)"""
+    pass B) + the deferred column sums of the parameter-gradient partials.  -> dx, (d_bcdt, d_dw, d_hz, d_out, d_D).
+    ln = (norm.weight, norm.bias, rstd_mean): x is the block's input and the kernels apply LayerNorm1D while they stage it
+    (kmu_mixer_bwd_stage); dx is then the gradient with respect to the normalised x."""
     lib = _lib.load()
     B, C, N, Hs = dims
     dev = x.device
@@ -744,8 +746,14 @@ def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_
     fn, tail = lib.kmu_hsmssd_bwd_stage, (st,)
     if x3:
         fn, tail = lib.kmu_hsmssd_bwd_stage_x3_pk, (1, _ptr(_hsm_pack(pack_ok, w_bcdt, w_dw, C, st)), st)
+    head = (_ptr(x),)
+    if ln is not None:
+        if not x3:
+            raise RuntimeError("kmunet: LayerNorm-on-load in the HSMSSD backward needs the split-bf16 kernels (KMU_K2_MATH != f32)")
+        fn, head = lib.kmu_mixer_bwd_stage, (_ptr(x), _ptr(ln[0]), _ptr(ln[1]), _ptr(ln[2]))
+        tail = (1, _ptr(_hsm_pack(pack_ok, w_bcdt, w_dw, C, st)), st)
     for stage, nm in enumerate(("hsmssd_bwd_passA", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
-        _lib.check(_call((nm + ("_x3" if x3 and stage == 0 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
+        _lib.check(_call((nm + ("_x3" if x3 and stage == 0 else ""), (B, C, Hs)), fn, *head, _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
                          _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
                          _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, *tail), "kmu_hsmssd_bwd_stage")
     mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
@@ -847,8 +855,7 @@ class MixerFn(torch.autograd.Function):
         lw = lb = xn = stats = None
         if ln:
             lw, lb = _f32c(ln_w, "norm.weight").reshape(-1), _f32c(ln_b, "norm.bias").reshape(-1)
-            if need_bwd:          # the backward kernels read the normalised x; inference skips the store
-                xn = torch.empty_like(x)
+            if need_bwd:          # the backward kernels re-derive the normalised x from x and these (rstd, mean) pairs
                 stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32)
         y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
         h = torch.empty(B, C, N, device=dev, dtype=torch.float32)
@@ -864,7 +871,7 @@ class MixerFn(torch.autograd.Function):
                              _ptr(tk), B, C, N, Hs, stage, 1, st), "kmu_mixer_fwd_stage")
         ctx.ln = ln
         if ln:
-            ctx.save_for_backward(x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state)
+            ctx.save_for_backward(x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state)
             ctx.lnshape = ln_w.shape
             ctx.defer_ln = _leaf(ln_w, ln_b)
         else:
@@ -881,15 +888,16 @@ class MixerFn(torch.autograd.Function):
     def backward(ctx, dy, dh, dalias=None):
         lib = _lib.load()
         if ctx.ln:
-            x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+            x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+            ln = (lw, lb, stats)
         else:
             x, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
-            xn = x
+            ln = None
         B, C, N, Hs = ctx.dims
         if dy is None and dh is None:                 # only the alias was used
             return (dalias,) + (None,) * 10
-        dxn, (d_bcdt, d_dw, d_hz, d_out, d_D) = _hsmssd_backward(xn, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, ctx.dims, ctx.pack_ok,
-                                                                 ctx.defer_wgrad)
+        dxn, (d_bcdt, d_dw, d_hz, d_out, d_D) = _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, ctx.dims, ctx.pack_ok,
+                                                                 ctx.defer_wgrad, ln)
         if not ctx.ln:
             if dalias is not None:
                 dxn = dxn + dalias
