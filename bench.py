@@ -98,6 +98,19 @@ def _kernel_model(name, shape):
         if base.endswith("bwd_weights"):
             byts = 4.0 * B * H * W * (Cin + Cout) + 4.0 * 81 * Cin * Cout
         return "mfma", flops, byts
+    if base.startswith("mixer_bwd"):       # csrc/hsmssd_bwdc.inc: the K2 backward with the C rows as a per-sample dense convolution
+        B, C, Hs = shape
+        L, N = Hs * Hs, 64
+        TT = -(-Hs // 8) * -(-Hs // (32 if C <= 32 else 16))
+        slabs = 4.0 * B * min(TT, max(1, 1024 // B)) * 9 * C * C          # G partials: one [C][9][C] slab per workgroup
+        if base.endswith("corr"):
+            return "hbm", B * L * 2.0 * 9 * C * C, 4.0 * B * C * L * 2 + slabs
+        if base.endswith("crows"):
+            return "hbm", B * 4.0 * 9 * C * C * N, slabs
+        proj, dw, mix = 2.0 * N * C, 2.0 * 9 * N, 2.0 * C * N
+        # pass B on the {B, dt} rows (projection recompute, dx, dW; stencil forward / transposed / weight gradient; dAB and its dx) + the
+        # dense transposed convolution of the C rows
+        return "hbm", B * L * (2 * 3 * proj + 2 * 3 * dw + 2 * mix + 2.0 * 9 * C * C), 4.0 * B * C * L * 3
     if base.startswith("hsmssd"):
         B, C, Hs = shape
         L, N = Hs * Hs, 64

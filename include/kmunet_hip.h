@@ -398,6 +398,11 @@ int kmu_add_n(const float* a, const float* b, const float* c, const float* d, fl
 int kmu_copy_multi(int count, const float* const* srcs, float* const* dsts, const long long* numel, kmu_stream_t stream);
 int kmu_colsum_multi(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols,
                      kmu_stream_t stream);
+/* the same with a row layout per array: strides[k] >= cols[k] elements between two partial rows (NULL = packed: column sums of a column
+ * range of a wider partial array); inner[k] / ostrides[k] (NULL = one run): rows in runs of inner[k], run i starting i * ostrides[k]
+ * elements in (the rows of one weight group of a grouped launch's [samples / G][G][tiles] partials) */
+int kmu_colsum_multi_strided(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols, const int* strides,
+                             const int* inner, const long long* ostrides, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * GroupNorm(G, C) over [B,C,HW]: StableHybridKANConv.pre_norm (KM_UNetV3_SH.py:57,73), TripleNorm.norm_h/w
@@ -616,9 +621,8 @@ int kmu_hsm_pack_multi(const void* device_table, int njobs, kmu_stream_t stream)
  *            sample's tiles in tile order, applies hz_proj / SiLU gate / out_proj (:52-55), writes `state` (layout of
  *            kmu_hsmssd_fwd: [M | S | hpre | hz | h2], read by kmu_hsmssd_bwd*), h, and the per-sample dense 3x3 weights
  *            M_b = h2 . Wc of stage 1 into ws.  No workgroup waits for another one.
- *   stage 1  pass 2: y = conv3x3(LayerNorm(x); M_b)  (== h2 . Cm, :57-59); optional outputs rstd_mean [B,L,2] (kmu_layernorm1d_bwd*,
- *            kmu_mixer_bwd_stage) and xn [B,C,L] (the normalised x: the `x` operand of kmu_hsmssd_bwd*; not needed with
- *            kmu_mixer_bwd_stage, which re-derives it on load).
+ *   stage 1  pass 2: y = conv3x3(LayerNorm(x); M_b)  (== h2 . Cm, :57-59); optional outputs xn [B,C,L] (the normalised x: the
+ *            `x` operand of kmu_mixer_bwd_stage / kmu_hsmssd_bwd*) and rstd_mean [B,L,2] (kmu_layernorm1d_bwd*).
  * ln_weight / ln_bias [groups, C] (both NULL: no LayerNorm, x is the mixer input itself, xn / rstd_mean must be NULL).
  * wpk: kmu_hsmssd_pack_x3 / kmu_hsm_pack_multi output (kmu_hsmssd_pack_elems elements).  groups as kmu_hsmssd_*_g.
  * tickets: B zero-initialised 32-bit words in device memory that no other in-flight launch uses; the kernel leaves them zero.
@@ -628,14 +632,21 @@ int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const float* ln_
                         const float* w_out, const float* D, const void* wpk, float* y, float* h, float* state, float* xn,
                         float* rstd_mean, void* ws, size_t ws_bytes, unsigned int* tickets, int B, int C, int N, int Hs, int stage,
                         int groups, kmu_stream_t stream);
-/* The K2 backward stages (kmu_hsmssd_bwd_stage_x3_pk: 0 = pass A, 1 = gate, 2 = pass B) with LayerNorm1D applied on load: x is the block's
- * input, rstd_mean [B,L,2] the statistics kmu_mixer_fwd_stage left, ln_weight / ln_bias [groups, C]; dx = gradient with respect to the
- * NORMALISED x (hand it to kmu_layernorm1d_bwd_add with x and rstd_mean).  The forward then need not store the normalised tensor. */
-int kmu_mixer_bwd_stage(const float* x, const float* ln_weight, const float* ln_bias, const float* rstd_mean, const float* dy, const float* dh,
-                        const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out, const float* D, const float* state,
-                        float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial,
-                        float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, const void* wpk,
-                        kmu_stream_t stream);
+/* The K2 backward behind kmu_mixer_fwd_stage (csrc/hsmssd_bwdc.inc), efficient_vim_init.py:33-61 differentiated with the C rows
+ * (:57-59, y = h2 . Cm) taken as the per-sample dense 3x3 convolution y = conv3x3(x; M_b) the forward ran:
+ *   stage 0  G_b[c][tap][c'] = sum_l dy[c][l] x[c'][l + tap - 1]   (split-bf16 matrix core, K = tokens; replaces pass A)
+ *   stage 1  dh2 = G . (w_dw (x) W_C), partial rows of d W_C [N, C] and d w_dw[C rows] [N, 9]: kmu_mixer_bwd_partials(B, C) rows each
+ *   stage 2  the gate stage (kmu_hsmssd_bwd_stage's stage 1)
+ *   stage 3  pass B on the {B, dt} rows + dx of the C rows (conv3x3^T(dy; M_b), M_b read from `state` as the forward left it);
+ *            the C-row sections of d_w_bcdt_partial / d_w_dw_partial ([.][N..2N)) are NOT written.
+ * x = the mixer's input (the NORMALISED tensor kmu_mixer_fwd_stage returns in xn when it folds a LayerNorm); `state` must come from
+ * kmu_mixer_fwd_stage.  Partial-row counts as kmu_hsmssd_bwd_stage_x3. */
+size_t kmu_mixer_bwd_ws_bytes(int B, int C, int N, int Hs);
+int kmu_mixer_bwd_partials(int B, int C);
+int kmu_mixer_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                        const float* w_out, const float* D, const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
+                        float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, float* d_wc_partial, float* d_dwc_partial, void* ws,
+                        size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, kmu_stream_t stream);
 void kmu_mixer_debug_rows(int rows); /* tools only: force pass 1's configuration (H | 16: 8 waves | 32: wide tiles; 0 = automatic) */
 void kmu_conv_debug_split(int mode); /* tools only: K1 / KxK forward at small images: 0 automatic, 1 never split Cout tiles over workgroups, 2 always */
 

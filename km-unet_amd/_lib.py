@@ -86,6 +86,7 @@ SIGNATURES = {
     "kmu_gate_mlp_fwd": (_I, [_P] * 7 + [_I] * 6 + [_P]),
     "kmu_gate_mlp_bwd": (_I, [_P] * 11 + [_I] * 6 + [_P]),
     "kmu_colsum_multi": (_I, [_I, _P, _P, _P, _P, _P]),
+    "kmu_colsum_multi_strided": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "kmu_copy_multi": (_I, [_I, _P, _P, _P, _P]),
     "kmu_add_n": (_I, [_P] * 5 + [_c.c_longlong, _P]),
     "kmu_relu_mask": (_I, [_P] * 3 + [_c.c_longlong, _P]),
@@ -141,7 +142,9 @@ SIGNATURES = {
     "kmu_hsmssd_bwd_stage_x3_pk": (_I, [_P] * 16 + [_Z] + [_I] * 6 + [_P, _P]),
     "kmu_mixer_fwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_mixer_fwd_stage": (_I, [_P] * 3 + [_c.c_float] + [_P] * 11 + [_Z, _P] + [_I] * 6 + [_P]),
-    "kmu_mixer_bwd_stage": (_I, [_P] * 19 + [_Z] + [_I] * 6 + [_P, _P]),
+    "kmu_mixer_bwd_ws_bytes": (_Z, [_I] * 4),
+    "kmu_mixer_bwd_partials": (_I, [_I] * 2),
+    "kmu_mixer_bwd_stage": (_I, [_P] * 18 + [_Z] + [_I] * 6 + [_P]),
     "kmu_mixer_debug_rows": (None, [_I]),
     "kmu_conv_debug_split": (None, [_I]),
     "kmu_gate_mlp_fwd_g": (_I, [_P] * 7 + [_I] * 7 + [_P]),

@@ -6,12 +6,15 @@
 
 namespace {
 
-constexpr int MAXA = 64, COLS = 32, PARTS = 8;     // 64 arrays: 1.8 KB of kernel arguments
+constexpr int MAXA = 64, COLS = 32, PARTS = 8;     // 64 arrays: 2.8 KB of kernel arguments
 
 struct ColsumArgs {
     const float* src[MAXA];
     float* dst[MAXA];
-    int rows[MAXA], cols[MAXA], blk0[MAXA + 1];
+    // row r of array k starts at (r / inner) * ostride + (r % inner) * stride: packed rows (stride = cols, inner = rows), a column
+    // range of a wider array (stride > cols), or the rows of ONE weight group of a [samples / G][G][tiles] partial array
+    int rows[MAXA], cols[MAXA], stride[MAXA], inner[MAXA], blk0[MAXA + 1];
+    long long ostride[MAXA];
     int n;
 };
 
@@ -21,18 +24,23 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumArgs a) {
     int k = 0;
     while (k + 1 < a.n && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
     const int c = (blockIdx.x - a.blk0[k]) * COLS + (threadIdx.x & (COLS - 1)), pt = threadIdx.x / COLS;
-    const int rows = a.rows[k], cols = a.cols[k];
+    const int rows = a.rows[k], cols = a.cols[k], rs = a.stride[k], inner = a.inner[k];
+    const long long os = a.ostride[k];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < cols) {
         const float* p = a.src[k] + c;
         int r = pt;
-        for (; r + 3 * PARTS < rows; r += 4 * PARTS) {
-            s0 += p[(size_t)r * cols];
-            s1 += p[(size_t)(r + PARTS) * cols];
-            s2 += p[(size_t)(r + 2 * PARTS) * cols];
-            s3 += p[(size_t)(r + 3 * PARTS) * cols];
+        if (inner >= rows) {
+            for (; r + 3 * PARTS < rows; r += 4 * PARTS) {
+                s0 += p[(size_t)r * rs];
+                s1 += p[(size_t)(r + PARTS) * rs];
+                s2 += p[(size_t)(r + 2 * PARTS) * rs];
+                s3 += p[(size_t)(r + 3 * PARTS) * rs];
+            }
+            for (; r < rows; r += PARTS) s0 += p[(size_t)r * rs];
+        } else {
+            for (; r < rows; r += PARTS) s0 += p[(size_t)(r / inner) * os + (size_t)(r % inner) * rs];
         }
-        for (; r < rows; r += PARTS) s0 += p[(size_t)r * cols];
     }
     part[pt][threadIdx.x & (COLS - 1)] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -207,23 +215,35 @@ extern "C" int kmu_copy_multi(int count, const float* const* srcs, float* const*
     return kmu::launch_status("copy_multi");
 }
 
-extern "C" int kmu_colsum_multi(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols,
-                                kmu_stream_t stream) {
+// strides[k] = elements between two partial rows of array k (>= cols[k]; NULL: every array is packed, stride = cols): column sums of a
+// column RANGE of a wider partial array without a copy.  inner[k] / ostrides[k] (NULL: one run): the rows come in runs of inner[k],
+// run i starting i * ostrides[k] elements in -- the rows of one weight group of a grouped launch's [samples / G][G][tiles] partials.
+extern "C" int kmu_colsum_multi_strided(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols,
+                                        const int* strides, const int* inner, const long long* ostrides, kmu_stream_t stream) {
     KMU_REQUIRE(n > 0 && n <= MAXA, "colsum_multi: %d arrays (1..%d supported)", n, MAXA);
-    KMU_REQUIRE(srcs && dsts && rows && cols, "colsum_multi: null pointer");
+    KMU_REQUIRE(srcs && dsts && rows && cols && ((inner == nullptr) == (ostrides == nullptr)), "colsum_multi: null pointer");
     ColsumArgs a;
     a.n = n;
     int blocks = 0;
     for (int k = 0; k < n; ++k) {
         KMU_REQUIRE(srcs[k] && dsts[k] && rows[k] > 0 && cols[k] > 0, "colsum_multi: array %d is empty or null", k);
+        KMU_REQUIRE(!strides || strides[k] >= cols[k], "colsum_multi: array %d has row stride %d < %d columns", k, strides ? strides[k] : 0, cols[k]);
+        KMU_REQUIRE(!inner || inner[k] > 0, "colsum_multi: array %d has runs of %d rows", k, inner ? inner[k] : 0);
         a.src[k] = srcs[k];
         a.dst[k] = dsts[k];
         a.rows[k] = rows[k];
         a.cols[k] = cols[k];
+        a.stride[k] = strides ? strides[k] : cols[k];
+        a.inner[k] = inner ? inner[k] : rows[k];
+        a.ostride[k] = ostrides ? ostrides[k] : 0;
         a.blk0[k] = blocks;
         blocks += kmu::cdiv(cols[k], COLS);
     }
     a.blk0[n] = blocks;
     hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return kmu::launch_status("colsum_multi");
+}
+extern "C" int kmu_colsum_multi(int n, const float* const* srcs, float* const* dsts, const int* rows, const int* cols,
+                                kmu_stream_t stream) {
+    return kmu_colsum_multi_strided(n, srcs, dsts, rows, cols, nullptr, nullptr, nullptr, stream);
 }

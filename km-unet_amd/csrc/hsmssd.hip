@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void hsm_fwd_pass1(const float* __restrict__ x
 // forward gate stage: one workgroup per batch element.
 // state layout per batch: [ M(64) | S(64) | hpre(C*64) | hz(2C*64) | h2(C*64) ]   ([c][n] row-major)
 // =================================================================================================
-__host__ __device__ inline size_t state_stride(int C) { return (size_t)2 * NS + (size_t)4 * C * NS; }
+// per-sample gate state: M[64] S[64] hpre[C][64] hz[2C][64] h2[C][64], then (written by the round-4 forward only) the dense 3x3 weights
+// M_b[C][9][C] of  y = conv3x3(x; M_b)  in fp32 for the backward pass (hsmssd_bwdc.inc)
+__host__ __device__ inline size_t state_stride(int C) { return (size_t)2 * NS + (size_t)4 * C * NS + (size_t)9 * C * C; }
 
 __device__ __forceinline__ float silu(float z) { return z / (1.f + __expf(-z)); }
 
@@ -696,13 +698,14 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
 #include "hsmssd_x3.inc"
 #include "hsmssd_v2.inc"
 #include "hsmssd_bwd.inc"
+#include "hsmssd_bwdc.inc"
 
 // backward on the matrix core: ws = [partA | dhpre | delta | composite weights (fragment order) | transposed composite weights]
 template <int C>
 int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
                 const float* w_out, const float* D, const float* state, float* dx, float* p_bcdt, float* p_dw, float* p_hz,
                 float* p_out, float* p_D, float* ws, int B, int Hs, int stages, hipStream_t st, int NG = 1,
-                const void* wpk_ext = nullptr, const float* ln_stats = nullptr, const float* ln_w = nullptr, const float* ln_b = nullptr) {
+                const void* wpk_ext = nullptr) {
     int txA;
     const int TA = tiles_x3<C>(Hs, &txA);
     float* partA = ws;
@@ -720,8 +723,7 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
             if (rc) return rc;
         }
         KMU_MAX_LDS(hsm_bwd_passA_x3<C>, la);
-        hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA, NG,
-                           ln_stats, ln_w, ln_b);
+        hipLaunchKernelGGL(hsm_bwd_passA_x3<C>, dim3(TA, B, chunk_split(TA * B)), dim3(256), la, st, x, dy, (const bf16x8*)wpk, partA, Hs, txA, NG);
         rc = kmu::launch_status("hsmssd_bwd passA (bf16x3)");
         if (rc) return rc;
     }
@@ -738,7 +740,7 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
             const size_t lbf = lds_passB<C>();
             KMU_MAX_LDS(hsm_bwd_passB<C>, lbf);
             hipLaunchKernelGGL(hsm_bwd_passB<C>, dim3(TBF, B, passB_split(C, Hs)), dim3(TileForB<C>::NW * 64), lbf, st, x, dy, w_bcdt, w_dw,
-                               state, dhp, delta, dx, p_bcdt, p_dw, Hs, txF, NG, ln_stats, ln_w, ln_b);
+                               state, dhp, delta, dx, p_bcdt, p_dw, Hs, txF, NG);
             rc = kmu::launch_status("hsmssd_bwd passB");
         }
     }
@@ -747,7 +749,7 @@ int bwd_impl_x3(const float* x, const float* dy, const float* dh, const float* w
 
 }  // namespace
 
-extern "C" size_t kmu_hsmssd_state_elems(int B, int C, int N) { return (size_t)B * ((size_t)2 * N + (size_t)4 * C * N); }
+extern "C" size_t kmu_hsmssd_state_elems(int B, int C, int N) { return (size_t)B * ((size_t)2 * N + (size_t)4 * C * N + (size_t)9 * C * C); }
 
 extern "C" size_t kmu_hsmssd_fwd_ws_bytes(int B, int C, int N, int Hs) {
     int tx;
@@ -903,11 +905,9 @@ static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, c
                              const float* w_hz, const float* w_out, const float* D, const float* state, float* dx,
                              float* d_w_bcdt_partial, float* d_w_dw_partial, float* d_w_hz_partial,
                              float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B, int C, int N,
-                             int Hs, int stages, kmu_stream_t stream, bool x3 = false, int groups = 1, const void* wpk = nullptr,
-                             const float* ln_stats = nullptr, const float* ln_w = nullptr, const float* ln_b = nullptr) {
+                             int Hs, int stages, kmu_stream_t stream, bool x3 = false, int groups = 1, const void* wpk = nullptr) {
     KMU_REQUIRE(groups >= 1 && (groups == 1 || x3) && B % groups == 0, "hsmssd_bwd: %d weight groups need the bf16x3 path and B %% groups == 0",
                 groups);
-    KMU_REQUIRE(!ln_stats || (x3 && ln_w && ln_b), "hsmssd_bwd: LayerNorm on load needs the bf16x3 path and both affine parameters");
     KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial &&
                     d_w_hz_partial && d_w_out_partial && d_D_partial && ws,
                 "hsmssd_bwd: null pointer");
@@ -922,12 +922,12 @@ static int hsmssd_bwd_stages(const float* x, const float* dy, const float* dh, c
     if (x3) {
         if (C == 16)
             return bwd_impl_x3<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk, ln_stats, ln_w, ln_b);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
         if (C == 32)
             return bwd_impl_x3<32>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk, ln_stats, ln_w, ln_b);
+                                   d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
         return bwd_impl_x3<64>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
-                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk, ln_stats, ln_w, ln_b);
+                               d_w_hz_partial, d_w_out_partial, d_D_partial, w, B, Hs, stages, st, groups, wpk);
     }
     if (C == 16)
         return bwd_impl<16>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial,
@@ -1028,19 +1028,36 @@ extern "C" int kmu_hsmssd_bwd_stage_x3_pk(const float* x, const float* dy, const
                              d_w_hz_partial, d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups, wpk);
 }
 
-// kmu_hsmssd_bwd_stage_x3_pk with LayerNorm1D applied on load: x is the block's input (NOT normalised), rstd_mean [B,L,2] the forward's
-// statistics (kmu_mixer_fwd_stage), ln_weight / ln_bias [groups, C].  dx is the gradient with respect to the NORMALISED x (feed it to
-// kmu_layernorm1d_bwd_add together with x and rstd_mean).
-extern "C" int kmu_mixer_bwd_stage(const float* x, const float* ln_weight, const float* ln_bias, const float* rstd_mean, const float* dy,
-                                   const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz, const float* w_out,
-                                   const float* D, const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
-                                   float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, void* ws, size_t ws_bytes, int B,
-                                   int C, int N, int Hs, int stage, int groups, const void* wpk, kmu_stream_t stream) {
-    KMU_REQUIRE(stage >= 0 && stage <= 2, "mixer_bwd_stage: stage must be 0 (pass A), 1 (gate) or 2 (pass B)");
-    KMU_REQUIRE(ln_weight && ln_bias && rstd_mean && wpk, "mixer_bwd_stage: null pointer");
-    return hsmssd_bwd_stages(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial, d_w_hz_partial,
-                             d_w_out_partial, d_D_partial, ws, ws_bytes, B, C, N, Hs, 1 << stage, stream, true, groups, wpk, rstd_mean,
-                             ln_weight, ln_bias);
+// ---- round 4: the K2 backward behind kmu_mixer_fwd_stage (csrc/hsmssd_bwdc.inc) -------------------------------------------------
+// The C rows handled as a per-sample dense convolution with the M_b the forward left in `state`.  stage 0: G = dy (*) x per sample
+// (replaces pass A), 1: the C rows' contractions of G (dh2, d W_C, d w_dw[C rows]), 2: gate, 3: pass B ({B, dt} rows + dx of the C rows).
+extern "C" size_t kmu_mixer_bwd_ws_bytes(int B, int C, int N, int Hs) {
+    (void)N;
+    return C == 16 ? bwdc_ws_bytes<16>(B, Hs) : (C == 32 ? bwdc_ws_bytes<32>(B, Hs) : bwdc_ws_bytes<64>(B, Hs));
+}
+extern "C" int kmu_mixer_bwd_partials(int B, int C) { return B * (C / (C == 16 ? 2 : 4)); }
+
+extern "C" int kmu_mixer_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
+                                   const float* w_out, const float* D, const float* state, float* dx, float* d_w_bcdt_partial,
+                                   float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial,
+                                   float* d_wc_partial, float* d_dwc_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage,
+                                   int groups, kmu_stream_t stream) {
+    KMU_REQUIRE(stage >= 0 && stage <= 3, "mixer_bwd_stage: stage must be 0 (correlation), 1 (C rows), 2 (gate) or 3 (pass B)");
+    KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial && d_w_hz_partial &&
+                    d_w_out_partial && d_D_partial && d_wc_partial && d_dwc_partial && ws,
+                "mixer_bwd_stage: null pointer");
+    KMU_REQUIRE(N == NS && (C == 16 || C == 32 || C == 64), "mixer_bwd_stage: C=%d, N=%d not instantiated (C in {16,32,64}, N = 64)", C, N);
+    KMU_REQUIRE(B >= 1 && Hs >= 1 && groups >= 1 && B % groups == 0, "mixer_bwd_stage: B=%d, Hs=%d, groups=%d", B, Hs, groups);
+    KMU_REQUIRE(ws_bytes >= kmu_mixer_bwd_ws_bytes(B, C, N, Hs), "mixer_bwd_stage: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* w = (float*)ws;
+#define KMU_BWDC_GO(CC)                                                                                                        \
+    return bwdc_impl<CC>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial, d_w_hz_partial, \
+                         d_w_out_partial, d_D_partial, d_wc_partial, d_dwc_partial, w, B, Hs, 1 << stage, st, groups)
+    if (C == 16) KMU_BWDC_GO(16);
+    if (C == 32) KMU_BWDC_GO(32);
+    KMU_BWDC_GO(64);
+#undef KMU_BWDC_GO
 }
 
 // ---- round 4: LayerNorm1D + HSMSSD forward in two launches (csrc/hsmssd_v2.inc) ---------------------------------------------

@@ -184,7 +184,7 @@ class HsmssdGFn(torch.autograd.Function):
 class MixerGFn(torch.autograd.Function):
     """(y [B*G, C, Hs, Hs], x') = HSMSSD(LayerNorm1D(x [B*G, C, L])) with G weight sets (sample b: set b % G), the two launches of
     csrc/hsmssd_v2.inc (ops.MixerFn, grouped); x' aliases x for the blend that follows: its gradient is added inside the LayerNorm
-    backward kernel.  Backward = the grouped bf16x3 HSMSSD backward (LayerNorm re-applied on load: kmu_mixer_bwd_stage) + the grouped LayerNorm backward."""
+    backward kernel.  Backward = ops._mixer_backward with G weight groups + the grouped LayerNorm backward."""
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, eps, w_bcdt, w_dw, w_hz, w_out, A, D):
@@ -206,7 +206,8 @@ class MixerGFn(torch.autograd.Function):
         lw, lb = _f32c(ln_w, "norm.weight").reshape(-1), _f32c(ln_b, "norm.bias").reshape(-1)
         dev = x.device
         need_bwd = any(ctx.needs_input_grad)
-        stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32) if need_bwd else None     # the backward re-derives LayerNorm(x) on load
+        xn = torch.empty_like(x) if need_bwd else None
+        stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32) if need_bwd else None
         y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
         h = torch.empty(B, C, N, device=dev, dtype=torch.float32)
         state = torch.empty(lib.kmu_hsmssd_state_elems(B, C, N), device=dev, dtype=torch.float32)
@@ -217,9 +218,9 @@ class MixerGFn(torch.autograd.Function):
         tk = ops._tickets(dev, B)
         for stage, nm in enumerate(("hsmssd_fwd_pass1_v2", "hsmssd_fwd_pass2_v2")):
             _lib.check(_call((nm + "_g", (B, C, Hs)), lib.kmu_mixer_fwd_stage, _ptr(x), _ptr(lw), _ptr(lb), float(eps), _ptr(w_dw), _ptr(w_hz),
-                             _ptr(w_out), _ptr(D), _ptr(wpk), _ptr(y), _ptr(h), _ptr(state), None, _ptr(stats), _ptr(ws), nbytes,
+                             _ptr(w_out), _ptr(D), _ptr(wpk), _ptr(y), _ptr(h), _ptr(state), _ptr(xn), _ptr(stats), _ptr(ws), nbytes,
                              _ptr(tk), B, C, N, Hs, stage, G, st), "kmu_mixer_fwd_stage")
-        ctx.save_for_backward(x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state)
+        ctx.save_for_backward(x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state)
         ctx.set_materialize_grads(False)
         ctx.dims = (B, C, N, Hs)
         ctx.zero_A = ops._const_zeros(A)
@@ -229,40 +230,22 @@ class MixerGFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dalias):
         lib = _lib.load()
-        x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
+        x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
         B, C, N, Hs = ctx.dims
         L = Hs * Hs
         dev = x.device
         if dy is None:
             return (dalias,) + (None,) * 9
-        dy = _f32c(dy, "dy")
-        P = lib.kmu_hsmssd_bwd_partials_x3(B, C, Hs)
-        dxn = torch.empty_like(x)
-        p_bcdt = torch.empty(P, 3 * N, C, device=dev, dtype=torch.float32)
-        p_dw = torch.empty(P, 3 * N, 9, device=dev, dtype=torch.float32)
-        Gp = lib.kmu_hsmssd_gate_partials(B)
-        p_hz = torch.empty(Gp, 2 * C, C, device=dev, dtype=torch.float32)
-        p_out = torch.empty(Gp, C, C, device=dev, dtype=torch.float32)
-        p_D = torch.empty(Gp, device=dev, dtype=torch.float32)
-        nbytes = lib.kmu_hsmssd_bwd_ws_bytes_x3_g(B, C, N, Hs, G)
-        ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
-        st = _stream()
-        wpk = ops._hsm_pack(ctx.pack_ok, w_bcdt, w_dw, C, st, G)
-        for stage, nm in enumerate(("hsmssd_bwd_passA_x3", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):
-            _lib.check(_call((nm + "_g", (B, C, Hs)), lib.kmu_mixer_bwd_stage, _ptr(x), _ptr(lw), _ptr(lb), _ptr(stats), _ptr(dy), None,
-                             _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dxn), _ptr(p_bcdt), _ptr(p_dw),
-                             _ptr(p_hz), _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, G, _ptr(wpk), st), "kmu_mixer_bwd_stage")
+        dxn, parts = ops._mixer_backward(xn, dy, None, w_bcdt, w_dw, w_hz, w_out, D, state, ctx.dims, ctx.pack_ok, groups=G, tag="_g")
         mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        d_bcdt, d_dw, d_hz, d_out, d_D = mk(G, 3 * N * C), mk(G, 3 * N * 9), mk(G, 2 * C * C), mk(G, C * C), mk(G)
-        Bs, tb, gp = B // G, P // B, Gp // B    # partial rows are (sample b, tile / gate block): the group of a row is b % G
-
-        def job():
-            torch.sum(p_bcdt.view(Bs, G, tb, -1), dim=(0, 2), out=d_bcdt)
-            torch.sum(p_dw.view(Bs, G, tb, -1), dim=(0, 2), out=d_dw)
-            torch.sum(p_hz.view(Bs, G, gp, -1), dim=(0, 2), out=d_hz)
-            torch.sum(p_out.view(Bs, G, gp, -1), dim=(0, 2), out=d_out)
-            torch.sum(p_D.view(Bs, G, gp), dim=(0, 2), out=d_D)
-        _wgrad(job, ctx.defer_wgrad)
+        d_bcdt, d_dw, d_hz, d_out, d_D = mk(G, 3 * N, C), mk(G, 3 * N, 9), mk(G, 2 * C * C), mk(G, C * C), mk(G, 1)
+        Bs = B // G     # partial rows are (sample b, tile / gate block / channel slice): the group of a row is b % G
+        pairs = []
+        for g in range(G):
+            pairs += ops._mixer_colsum_pairs(parts, (d_bcdt[g], d_dw[g], d_hz[g], d_out[g], d_D[g]), N,
+                                             grp=lambda p, g=g: p.view(Bs, G, p.shape[0] // B, *p.shape[1:])[:, g])
+        _wgrad(lambda: ops.colsum(*[p for p, _ in pairs], outs=[o for _, o in pairs]), ctx.defer_wgrad)
+        st = _stream()
         # LayerNorm1D backward, the blend partner's gradient added in its epilogue
         addend = None if dalias is None else _f32c(dalias, "grad of the alias")
         rows = lib.kmu_layernorm1d_partials(B, C, L)
@@ -274,10 +257,9 @@ class MixerGFn(torch.autograd.Function):
         dw, db = mk(G, C), mk(G, C)
         nb = rows // B                      # partial rows are (sample b, block): group of a row = b % G
 
-        def lnjob():
-            torch.sum(dwp.view(B // G, G, nb, C), dim=(0, 2), out=dw)
-            torch.sum(dbp.view(B // G, G, nb, C), dim=(0, 2), out=db)
-        _wgrad(lnjob, ctx.defer_ln)
+        lgrp = lambda p, g: p.view(B // G, G, nb, C)[:, g]
+        _wgrad(lambda: ops.colsum(*[lgrp(p, g) for g in range(G) for p in (dwp, dbp)], outs=[o[g] for g in range(G) for o in (dw, db)]),
+               ctx.defer_ln)
         return (dx, dw.view(ctx.lnshape), db.view(ctx.lnshape), None, d_bcdt.view(G * 3 * N, C, 1), d_dw.view(G * 3 * N, 1, 3, 3),
                 d_hz.view(G * 2 * C, C, 1), d_out.view(G * C, C, 1), ctx.zero_A, d_D.view(G))
 

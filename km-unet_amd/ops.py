@@ -148,6 +148,29 @@ def flush_wgrad_jobs(final=True):
             _issue_batched(batch)       # on the joining stream, behind every job's first stage
 
 
+def _cs_desc(p, o):
+    """(rows, cols, row stride, rows per run, run stride) of partial array p whose column sum is o: p = [rows, *o.shape] packed, a column
+    range p_full[:, a:b] of a packed array, or [runs, rows per run, *o.shape] (one weight group of a grouped launch's partials)."""
+    cols = max(1, o.numel())
+    if p.shape[0] * cols == p.numel():
+        if p.shape[0] > 1 and not p[0].is_contiguous():
+            raise RuntimeError("colsum: the rows of a partial array must be contiguous")
+        return p.shape[0], cols, (int(p.stride(0)) if p.shape[0] > 1 else cols), p.shape[0], 0
+    if p.dim() < 3 or p.shape[0] * p.shape[1] * cols != p.numel() or not p[0, 0].is_contiguous():
+        raise RuntimeError("colsum: partial %s (strides %s) against result %s" % (tuple(p.shape), tuple(p.stride()), tuple(o.shape)))
+    return p.shape[0] * p.shape[1], cols, (int(p.stride(1)) if p.shape[1] > 1 else cols), p.shape[1], int(p.stride(0))
+
+
+def _cs_launch(pairs, st):
+    import ctypes
+    n = len(pairs)
+    vp, ip, lp = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
+    d = [_cs_desc(p, o) for p, o in pairs]
+    return _lib.load().kmu_colsum_multi_strided(n, vp(*[p.data_ptr() for p, _ in pairs]), vp(*[o.data_ptr() for _, o in pairs]),
+                                                ip(*[x[0] for x in d]), ip(*[x[1] for x in d]), ip(*[x[2] for x in d]),
+                                                ip(*[x[3] for x in d]), lp(*[x[4] for x in d]), st)
+
+
 def colsum(*partials, outs=None):
     """Column sums of per-workgroup partial arrays [rows, ...] -> [...] for up to 8 arrays in ONE launch
     (csrc/colsum.hip): the second stage of every deterministic two-stage parameter-gradient reduction.
@@ -161,13 +184,8 @@ def colsum(*partials, outs=None):
         _WG_BATCH["colsum"].extend(zip(parts, outs))
         it = iter(outs)
         return [None if p is None else next(it) for p in partials]
-    n = len(parts)
-    srcs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts])
-    dsts = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
-    rows = (ctypes.c_int * n)(*[p.shape[0] for p in parts])
-    cols = (ctypes.c_int * n)(*[max(1, o.numel()) for o in outs])
-    _lib.check(_call(("colsum_multi", tuple(int(p.numel()) for p in parts)), lib.kmu_colsum_multi, n, srcs, dsts, rows, cols,
-                     _stream()), "kmu_colsum_multi")
+    _lib.check(_call(("colsum_multi", tuple(int(p.numel()) for p in parts)), _cs_launch, list(zip(parts, outs)), _stream()),
+               "kmu_colsum_multi")
     it = iter(outs)
     return [None if p is None else next(it) for p in partials]
 
@@ -304,8 +322,7 @@ def _issue_batched(batch):
         ch = cs[i:i + 64]
         n = len(ch)
         vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
-        _lib.check(lib.kmu_colsum_multi(n, vp(*[p.data_ptr() for p, _ in ch]), vp(*[o.data_ptr() for _, o in ch]),
-                                        ip(*[p.shape[0] for p, _ in ch]), ip(*[max(1, o.numel()) for _, o in ch]), st), "kmu_colsum_multi")
+        _lib.check(_cs_launch(ch, st), "kmu_colsum_multi")
 
 
 # ------------------------------------------------------------------------------------------ weight packs, once per step
@@ -721,11 +738,9 @@ def _hsm_pack(ok, w_bcdt, w_dw, C, st, groups=1):
                    lambda buf: _lib.check(lib.kmu_hsmssd_pack_x3(_ptr(w_bcdt), _ptr(w_dw), _ptr(buf), C, groups, st), "kmu_hsmssd_pack_x3"))
 
 
-def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, defer, ln=None):
-    """Backward of HSMSSD.forward given the (normalised) input x, the saved gate state and dy / dh: three launches (pass A, gate,
-    pass B) + the deferred column sums of the parameter-gradient partials.  -> dx, (d_bcdt, d_dw, d_hz, d_out, d_D).
-    ln = (norm.weight, norm.bias, rstd_mean): x is the block's input and the kernels apply LayerNorm1D while they stage it
-    (kmu_mixer_bwd_stage); dx is then the gradient with respect to the normalised x."""
+def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, defer):
+    """Backward of HSMSSD.forward given the input x, the saved gate state and dy / dh: three launches (pass A, gate,
+    pass B) + the deferred column sums of the parameter-gradient partials.  -> dx, (d_bcdt, d_dw, d_hz, d_out, d_D)"""
     lib = _lib.load()
     B, C, N, Hs = dims
     dev = x.device
@@ -746,20 +761,83 @@ def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_
     fn, tail = lib.kmu_hsmssd_bwd_stage, (st,)
     if x3:
         fn, tail = lib.kmu_hsmssd_bwd_stage_x3_pk, (1, _ptr(_hsm_pack(pack_ok, w_bcdt, w_dw, C, st)), st)
-    head = (_ptr(x),)
-    if ln is not None:
-        if not x3:
-            raise RuntimeError("kmunet: LayerNorm-on-load in the HSMSSD backward needs the split-bf16 kernels (KMU_K2_MATH != f32)")
-        fn, head = lib.kmu_mixer_bwd_stage, (_ptr(x), _ptr(ln[0]), _ptr(ln[1]), _ptr(ln[2]))
-        tail = (1, _ptr(_hsm_pack(pack_ok, w_bcdt, w_dw, C, st)), st)
     for stage, nm in enumerate(("hsmssd_bwd_passA", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
-        _lib.check(_call((nm + ("_x3" if x3 and stage == 0 else ""), (B, C, Hs)), fn, *head, _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
+        _lib.check(_call((nm + ("_x3" if x3 and stage == 0 else ""), (B, C, Hs)), fn, _ptr(x), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
                          _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz),
                          _ptr(p_out), _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, *tail), "kmu_hsmssd_bwd_stage")
     mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
     d_bcdt, d_dw, d_hz, d_out, d_D = mk(3 * N, C), mk(3 * N, 9), mk(2 * C, C), mk(C, C), mk(1)
     _wgrad(lambda: colsum(p_bcdt, p_dw, p_hz, p_out, p_D.view(G, 1), outs=[d_bcdt, d_dw, d_hz, d_out, d_D]), defer)
     return dx, (d_bcdt.view(3 * N, C, 1), d_dw.view(3 * N, 1, 3, 3), d_hz.view(2 * C, C, 1), d_out.view(C, C, 1), d_D.view(1))
+
+
+_MIXER_BWD_STAGES = ("mixer_bwd_corr", "mixer_bwd_crows", "hsmssd_bwd_gate", "mixer_bwd_passB")
+# Widest channel count whose backward takes the C rows as a per-sample dense convolution (csrc/hsmssd_bwdc.inc).  G = dy (*) x is
+# 9 C^2 floats per partial against pass A's 64 C, and the C chunks are pass B's cheapest: measured alone (tools/time_k2_bwd.py,
+# profiles/r04_k2_backward_times.json) the whole backward goes 173 -> 147 us at C = 16, 105 -> 105 at C = 32 (one launch more) and
+# 292 -> 305 at C = 64 -- so only the 16-channel level takes this route; every C is instantiated and tested on both.
+MIXER_BWD_CROWS_MAXC = 16
+
+
+def _mixer_backward(xn, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, groups=1, tag=""):
+    """Backward behind MixerFn's forward given the (normalised) input, the saved gate state and dy / dh.  C <= MIXER_BWD_CROWS_MAXC:
+    the C rows as a per-sample dense convolution with the M_b the forward left in `state` (correlation G = dy (*) x, the C rows'
+    contractions of G, the gate stage, pass B on the {B, dt} rows); else pass A, gate, pass B on all rows.
+    -> dx, (column-sum inputs, rows of w_bcdt / w_dw they belong to): see _mixer_colsums."""
+    lib = _lib.load()
+    B, C, N, Hs = dims
+    dev = xn.device
+    dy = _f32c(dy, "dy") if dy is not None else torch.zeros(B, C, Hs, Hs, device=dev)
+    dh = _f32c(dh, "dh") if dh is not None else None
+    P = lib.kmu_hsmssd_bwd_partials_x3(B, C, Hs)
+    Gp = lib.kmu_hsmssd_gate_partials(B)
+    mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    dx = torch.empty_like(xn)
+    p_bcdt, p_dw = mk(P, 3 * N, C), mk(P, 3 * N, 9)
+    p_hz, p_out, p_D = mk(Gp, 2 * C, C), mk(Gp, C, C), mk(Gp)
+    st = _stream()
+    if C > MIXER_BWD_CROWS_MAXC:
+        nbytes = lib.kmu_hsmssd_bwd_ws_bytes_x3_g(B, C, N, Hs, groups)
+        ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
+        wpk = _hsm_pack(pack_ok, w_bcdt, w_dw, C, st, groups)
+        for stage, nm in enumerate(("hsmssd_bwd_passA_x3", "hsmssd_bwd_gate", "hsmssd_bwd_passB")):   # one kernel per call
+            _lib.check(_call((nm + tag, (B, C, Hs)), lib.kmu_hsmssd_bwd_stage_x3_pk, _ptr(xn), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw),
+                             _ptr(w_hz), _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz), _ptr(p_out),
+                             _ptr(p_D), _ptr(ws), nbytes, B, C, N, Hs, stage, groups, _ptr(wpk), st), "kmu_hsmssd_bwd_stage_x3_pk")
+        return dx, (p_bcdt, p_dw, p_hz, p_out, p_D, None, None)
+    Pc = lib.kmu_mixer_bwd_partials(B, C)
+    pc_W, pc_dw = mk(Pc, N, C), mk(Pc, N, 9)          # the C-row sections [:, N:2N] of p_bcdt / p_dw stay unwritten: these carry them
+    nbytes = lib.kmu_mixer_bwd_ws_bytes(B, C, N, Hs)
+    ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
+    for stage, nm in enumerate(_MIXER_BWD_STAGES):                                   # one kernel per call
+        _lib.check(_call((nm + tag, (B, C, Hs)), lib.kmu_mixer_bwd_stage, _ptr(xn), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
+                         _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz), _ptr(p_out), _ptr(p_D), _ptr(pc_W),
+                         _ptr(pc_dw), _ptr(ws), nbytes, B, C, N, Hs, stage, groups, st), "kmu_mixer_bwd_stage")
+    return dx, (p_bcdt, p_dw, p_hz, p_out, p_D, pc_W, pc_dw)
+
+
+def _mixer_colsum_pairs(parts, outs, N, grp=lambda p: p):
+    """(partial, result) pairs of one weight group for ops.colsum: parts from _mixer_backward, outs = (d_bcdt [3N, C], d_dw [3N, 9],
+    d_hz, d_out, d_D); grp selects the group's rows of a partial array (grouped launches)."""
+    p_bcdt, p_dw, p_hz, p_out, p_D, pc_W, pc_dw = parts
+    d_bcdt, d_dw, d_hz, d_out, d_D = outs
+    tail = [(grp(p_hz), d_hz), (grp(p_out), d_out), (grp(p_D.view(-1, 1)), d_D)]
+    if pc_W is None:
+        return [(grp(p_bcdt), d_bcdt), (grp(p_dw), d_dw)] + tail
+    pb, pd = grp(p_bcdt), grp(p_dw)
+    return [(pb[..., :N, :], d_bcdt[:N]), (pb[..., 2 * N:, :], d_bcdt[2 * N:]), (grp(pc_W), d_bcdt[N:2 * N]), (pd[..., :N, :], d_dw[:N]),
+            (pd[..., 2 * N:, :], d_dw[2 * N:]), (grp(pc_dw), d_dw[N:2 * N])] + tail
+
+
+def _mixer_colsums(parts, N, C, defer):
+    """Column sums of _mixer_backward's partial arrays (one weight group) in one deferred launch -> (d_bcdt, d_dw, d_hz, d_out, d_D)."""
+    dev = parts[0].device
+    mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    outs = (mk(3 * N, C), mk(3 * N, 9), mk(2 * C, C), mk(C, C), mk(1))
+    pairs = _mixer_colsum_pairs(parts, outs, N)
+    _wgrad(lambda: colsum(*[p for p, _ in pairs], outs=[o for _, o in pairs]), defer)
+    d_bcdt, d_dw, d_hz, d_out, d_D = outs
+    return d_bcdt.view(3 * N, C, 1), d_dw.view(3 * N, 1, 3, 3), d_hz.view(2 * C, C, 1), d_out.view(C, C, 1), d_D.view(1)
 
 
 class HsmssdFn(torch.autograd.Function):
@@ -855,7 +933,8 @@ class MixerFn(torch.autograd.Function):
         lw = lb = xn = stats = None
         if ln:
             lw, lb = _f32c(ln_w, "norm.weight").reshape(-1), _f32c(ln_b, "norm.bias").reshape(-1)
-            if need_bwd:          # the backward kernels re-derive the normalised x from x and these (rstd, mean) pairs
+            if need_bwd:          # the backward kernels read the normalised x; inference skips the store
+                xn = torch.empty_like(x)
                 stats = torch.empty(B, L, 2, device=dev, dtype=torch.float32)
         y = torch.empty(B, C, Hs, Hs, device=dev, dtype=torch.float32)
         h = torch.empty(B, C, N, device=dev, dtype=torch.float32)
@@ -871,7 +950,7 @@ class MixerFn(torch.autograd.Function):
                              _ptr(tk), B, C, N, Hs, stage, 1, st), "kmu_mixer_fwd_stage")
         ctx.ln = ln
         if ln:
-            ctx.save_for_backward(x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state)
+            ctx.save_for_backward(x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state)
             ctx.lnshape = ln_w.shape
             ctx.defer_ln = _leaf(ln_w, ln_b)
         else:
@@ -888,16 +967,15 @@ class MixerFn(torch.autograd.Function):
     def backward(ctx, dy, dh, dalias=None):
         lib = _lib.load()
         if ctx.ln:
-            x, lw, lb, stats, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
-            ln = (lw, lb, stats)
+            x, lw, stats, xn, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
         else:
             x, w_bcdt, w_dw, w_hz, w_out, D, state = ctx.saved_tensors
-            ln = None
+            xn = x
         B, C, N, Hs = ctx.dims
         if dy is None and dh is None:                 # only the alias was used
             return (dalias,) + (None,) * 10
-        dxn, (d_bcdt, d_dw, d_hz, d_out, d_D) = _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, ctx.dims, ctx.pack_ok,
-                                                                 ctx.defer_wgrad, ln)
+        dxn, parts = _mixer_backward(xn, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, ctx.dims, ctx.pack_ok)
+        d_bcdt, d_dw, d_hz, d_out, d_D = _mixer_colsums(parts, N, C, ctx.defer_wgrad)
         if not ctx.ln:
             if dalias is not None:
                 dxn = dxn + dalias

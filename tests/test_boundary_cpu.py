@@ -36,7 +36,7 @@ def test_header_symbols_exported():
     # size queries are pure host arithmetic and may be called without a GPU
     assert lib.kmu_kan_pack_fwd_elems(16, 16) == 4 * 81 * 1 * 64
     assert lib.kmu_kan_pack_bwd_elems(64, 32) == 8 * 81 * 4 * 64
-    assert lib.kmu_hsmssd_state_elems(2, 16, 64) == 2 * (128 + 4 * 16 * 64)
+    assert lib.kmu_hsmssd_state_elems(2, 16, 64) == 2 * (128 + 4 * 16 * 64 + 9 * 16 * 16)      # + M_b [C][9][C] of the round-4 forward
 
 
 @pytest.mark.parametrize("fname,variant,nc", [("manifest_sh_nc20.txt", "SH", 20), ("manifest_laps_nc3.txt", "LAPS", 3)])

@@ -262,6 +262,43 @@ def test_mixer_ln_vs_oracle(B, C, Hs, rows):
     _report("mixer_ln %s rows=%d" % ((B, C, Hs), rows), **errs)
 
 
+@pytest.mark.parametrize("B,C,Hs", [(2, 16, 40), (3, 32, 17), (2, 64, 16), (8, 16, 128)])
+def test_mixer_backward_crows_as_dense_conv_matches_row_kernels(B, C, Hs):
+    """The two backward routes behind MixerFn (ops.MIXER_BWD_CROWS_MAXC): the C rows as a per-sample dense convolution
+    (csrc/hsmssd_bwdc.inc) and pass A / pass B on all 192 rows -- every C on both routes, against the fp32 oracle and against each other."""
+    from oracle import hsmssd as oh
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C * 77 + Hs)
+    N, L = 64, Hs * Hs
+    x = (torch.randn(B, C, L, generator=gen) * 1.7 + 0.3).requires_grad_(True)
+    lw, lb = (torch.randn(1, C, 1, generator=gen) * 0.3 + 1).requires_grad_(True), (torch.randn(1, C, 1, generator=gen) * 0.2).requires_grad_(True)
+    w = {"w_bcdt": torch.randn(3 * N, C, 1, generator=gen) / C ** 0.5, "w_dw": torch.randn(3 * N, 1, 3, 3, generator=gen) * 0.4,
+         "w_hz": torch.randn(2 * C, C, 1, generator=gen) / C ** 0.5, "w_out": torch.randn(C, C, 1, generator=gen) / C ** 0.5,
+         "A": torch.rand(N, generator=gen) * 15 + 1, "D": torch.ones(1) + 0.3}
+    w = {k: v.requires_grad_(True) for k, v in w.items()}
+    gy, gh = torch.randn(B, C, Hs, Hs, generator=gen), torch.randn(B, C, N, generator=gen) * 0.1
+    mu = x.mean(1, keepdim=True)
+    xn = (x - mu) / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5) * lw + lb        # vim_utils_init.py:50-59
+    yo, ho = oh.hsmssd(xn, *w.values(), state_dim=N)
+    ((yo * gy).sum() + (ho * gh).sum()).backward()
+    ref = dict({k: v.grad for k, v in dict(w, lw=lw, lb=lb).items() if k != "A"}, x=x.grad)
+    saved, got = ops.MIXER_BWD_CROWS_MAXC, {}
+    try:
+        for mode in (64, 0):
+            ops.MIXER_BWD_CROWS_MAXC = mode
+            xd = x.detach().to(DEV).requires_grad_(True)
+            pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in dict(w, lw=lw, lb=lb).items()}
+            y, h = ops.mixer_ln(xd, pd["lw"], pd["lb"], 1e-5, *[pd[k] for k in w])
+            ((y * gy.to(DEV)).sum() + (h * gh.to(DEV)).sum()).backward()
+            got[mode] = dict({k: v.grad for k, v in pd.items() if k != "A"}, x=xd.grad)
+            _report("mixer backward %s, C rows %s" % ((B, C, Hs), "as a dense conv" if mode else "in pass A / pass B"),
+                    **{"d_" + k: rel_err(got[mode][k], ref[k]) for k in ref})
+    finally:
+        ops.MIXER_BWD_CROWS_MAXC = saved
+    errs = {k: rel_err(got[64][k], got[0][k]) for k in ref}
+    assert max(errs.values()) < 1e-4, errs
+
+
 @pytest.mark.parametrize("name", ["k2_c16", "k2_c32", "k2_c64"])
 def test_k2_golden_backward(name):
     g = load_golden(name)

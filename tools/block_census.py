@@ -10,7 +10,8 @@ dev = "cuda"
 m = km_unet_amd.KM_UNetV3(num_classes=5).to(dev).train()
 name = sys.argv[1]
 mod, shape = {"bridge": (m.bridge_attention, (8, 64, 16, 16)), "lca1": (m.lca1, (8, 16, 64, 64)), "kan1": (m.enc1[0], (8, 16, 128, 128)),
-              "iwp1": (m.enc1[2], (8, 16, 128, 128)), "dec1": (m.dec1, (8, 64, 16, 16)), "vim32": (m.enc2[1], (8, 32, 64, 64))}[name]
+              "iwp1": (m.enc1[2], (8, 16, 128, 128)), "dec1": (m.dec1, (8, 64, 16, 16)), "vim32": (m.enc2[1], (8, 32, 64, 64)), "vim64": (m.enc3[1], (8, 64, 32, 32)),
+              "vim16": (m.enc1[1], (8, 16, 128, 128)), "kan3": (m.enc3[0], (8, 32, 32, 32))}[name]
 x = torch.randn(*shape, device=dev, requires_grad=True)
 params = [p for p in mod.parameters() if p.requires_grad]
 def step():
@@ -27,5 +28,5 @@ for e in prof.key_averages():
         rows.append((dt, e.count, e.key[:110]))
 rows.sort(reverse=True)
 print("%s: %d kernels, %.1f us device time" % (name, sum(r[1] for r in rows), sum(r[0] for r in rows)))
-for dt, n, k in rows[:60]:
+for dt, n, k in rows[:int(os.environ.get("TOP", "60"))]:
     print("%8.1f us %3d x  %s" % (dt, n, k))

@@ -35,7 +35,19 @@ specs = {
     "up2": (lambda: m.dec2[0], [(B, 64, 32, 32)]),
     "up3": (lambda: m.dec3[0], [(B, 64, 64, 64)]),
     "msf1": (lambda: m.attention1[0], None),
+    "dec2": (lambda: _Seq(m.dec2, lambda d, x: d[2](km_unet_amd.nn.conv3x3(d[0](x), d[1]))), [(B, 64, 32, 32)]),
+    "dec3": (lambda: _Seq(m.dec3, lambda d, x: km_unet_amd.nn.conv3x3(d[2](km_unet_amd.nn.conv3x3(d[0](x), d[1])), d[3])), [(B, 64, 64, 64)]),
+    "lca2": (lambda: m.lca2, [(B, 32, 32, 32)]),
 }
+class _Seq(torch.nn.Module):
+    """a decoder stage run the way KM_UNetV3.forward runs it"""
+    def __init__(self, d, fn):
+        super().__init__()
+        self.d, self.fn = d, fn
+    def forward(self, x):
+        return self.fn(self.d, x)
+
+
 for name in sys.argv[1:]:
     mod, shapes = specs[name][0](), specs[name][1]
     if shapes is None:       # MultiScaleFusion takes a list of three features
