@@ -163,6 +163,11 @@ def _kernel_model(name, shape):
     if name.startswith("lca_"):
         B, C, HW = shape
         return "hbm", 0.0, t * B * C * HW * (2 if name.endswith("fwd") else 3)
+    if name.startswith(("dagem_fwd", "dagem_bwd")):       # csrc/dagem_fused.hip: [B,C,HW]-sized tensors read / written per stage
+        B, C, H, W = shape
+        tensors = {"dagem_fwd0": 4, "dagem_fwd1": 5, "dagem_fwd2": 4, "dagem_fwd3": 2, "dagem_bwd0": 2, "dagem_bwd1": 6, "dagem_bwd2": 8,
+                   "dagem_bwd3": 9, "dagem_bwd4": 7}[name]
+        return "hbm", 2.0 * B * H * W * C * C * 3, t * B * C * H * W * tensors
     if name.startswith("dagem_edges"):
         B, C, H, W = shape
         return "hbm", 0.0, t * B * C * H * W * (5 if name.endswith("fwd") else 6)

@@ -532,6 +532,46 @@ int kmu_dagem_edges_fwd(const float* x, float* edge, int B, int C, int H, int W,
 int kmu_dagem_edges_bwd(const float* x, const float* d_edge, float* dx, int B, int C, int H, int W, kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * DAGEM (DAGEM_md.py:56-111) without its deformable convolution, one launch per BatchNorm boundary (csrc/dagem_fused.hip).
+ *   forward  stage 0  edges (:56-62), a_pre = edge_aggregation_func[0](edge rows) (:65), u_pre = edge_update_func[0]([x | edge] rows) (:74-81)
+ *            stage 1  agg = ReLU(BN(a_pre)); v_pre = vertex_update_func[0]([x | agg] rows) (:68-72); r_pre = update_edge_reduce_func[0](ReLU(BN(u_pre))) (:82)
+ *            stage 2  z = final_aggregation_layer[0]([dconv + x | ReLU(BN(v_pre)) * ReLU(BN(r_pre))]) (:85-103), dconv = deform_conv(x, offset)
+ *            stage 3  out = ReLU(BN(z)) (:104)
+ *   backward stages 4..8 (given g_out): BN sums of the final layer; dz -> g_dd (gradient of dconv, and of the residual x), d W_f partials;
+ *            dv_pre / dr_pre -> d W_v, d w_r partials; da_pre / du_pre -> d w_a, d W_e partials, de; dx = edge adjoint + the other pieces.
+ * BatchNorm order in the five-element arrays: 0 edge_aggregation_func[1], 1 vertex_update_func[1], 2 edge_update_func[1],
+ * 3 update_edge_reduce_func[1], 4 final_aggregation_layer[1].  training != 0: batch statistics; running statistics and the batch counter
+ * are updated by stages 1..3 (momentum must be a number).  Weights in their nn.Module layouts: wa / wr [1,4], wv / we [C/2, 2C],
+ * wf [C, C + C/2]; biases ba / br [1], bv / be [C/2].  Saved activations (caller-allocated, forward -> backward): a_pre [B,C,P],
+ * u_pre [B,C/2,P,4], v_pre / r_pre [B,C/2,P], z [B,C,P], bnstat [5,C,2] (mean, rstd), P = H W.  part / part_bwd:
+ * kmu_dagem_part_floats() floats each (per-workgroup BatchNorm partial sums).  Optional outputs (may be NULL): agg_out [B,C,P],
+ * u_out [B,C/2,P,4], vert_out / ue_out [B,C/2,P] -- the post-ReLU activations (parity tooling reads the branch masks off them).
+ * Backward scratch: g_dd, ga, dxb [B,C,P]; gv, gr, dr_pre [B,C/2,P]; de [B,C,P,4].  Parameter gradients: d_gamma / d_beta final;
+ * p_* = partial rows, kmu_dagem_tiles(B,H,W) of them, to be column-summed (kmu_colsum_multi): p_wf [.,C,C+C/2], p_wv / p_we [.,C/2,2C],
+ * p_bv / p_be [.,C/2], p_wa / p_wr [.,5] = (d weight[0..3], d bias).  C in {32, 64} (kmu_dagem_supported).
+ * ------------------------------------------------------------------------------------ */
+typedef struct kmu_dagem_args {
+    int B, C, H, W, training;
+    float eps[5], momentum[5];
+    const float *x, *dconv;
+    const float *wa, *ba, *wv, *bv, *we, *be, *wr, *br, *wf;
+    const float *gamma[5], *beta[5];
+    float *running_mean[5], *running_var[5];
+    long long* num_batches_tracked[5];
+    float *a_pre, *u_pre, *v_pre, *r_pre, *z, *out, *bnstat, *part, *part_bwd;
+    float *agg_out, *u_out, *vert_out, *ue_out;
+    const float* g_out;
+    float *g_dd, *gv, *gr, *ga, *dr_pre, *dxb, *de, *dx;
+    float *d_gamma[5], *d_beta[5];
+    float *p_wf, *p_wv, *p_bv, *p_we, *p_be, *p_wa, *p_wr;
+} kmu_dagem_args;
+size_t kmu_dagem_args_bytes(void); /* sizeof(kmu_dagem_args) as the library was built: a binding checks its own layout against it */
+int kmu_dagem_supported(int C);
+int kmu_dagem_tiles(int B, int H, int W);
+size_t kmu_dagem_part_floats(int B, int C, int H, int W);
+int kmu_dagem_stage(const kmu_dagem_args* args, int stage, kmu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * TripleNorm (KM_UNetV3_SH.py:266-284): y = (GroupNorm_h(x) + GroupNorm_w(x) + LayerNorm_c(x)) / 3 on x [B,C,HW], C in {16,32,64}.
  * norm_h / norm_w = nn.GroupNorm(1, C) share their statistics (one group: invariant under the H/W transpose of the 'height' branch);
  * norm_c = nn.LayerNorm(C) on the channels-last view = per-pixel statistics over C.

@@ -15,6 +15,17 @@ if os.environ.get("KMU_LIB_VARIANT"):      # development: an alternative build m
 _c = ctypes
 _P, _I, _Z = _c.c_void_p, _c.c_int, _c.c_size_t
 
+class DagemArgs(_c.Structure):
+    """struct kmu_dagem_args of include/kmunet_hip.h (field for field)."""
+    _fields_ = ([(n, _I) for n in ("B", "C", "H", "W", "training")] + [("eps", _c.c_float * 5), ("momentum", _c.c_float * 5)] +
+                [(n, _P) for n in ("x", "dconv", "wa", "ba", "wv", "bv", "we", "be", "wr", "br", "wf")] +
+                [(n, _P * 5) for n in ("gamma", "beta", "running_mean", "running_var", "num_batches_tracked")] +
+                [(n, _P) for n in ("a_pre", "u_pre", "v_pre", "r_pre", "z", "out", "bnstat", "part", "part_bwd", "agg_out", "u_out", "vert_out",
+                                   "ue_out", "g_out", "g_dd", "gv", "gr", "ga", "dr_pre", "dxb", "de", "dx")] +
+                [(n, _P * 5) for n in ("d_gamma", "d_beta")] +
+                [(n, _P) for n in ("p_wf", "p_wv", "p_bv", "p_we", "p_be", "p_wa", "p_wr")])
+
+
 # name -> (restype, argtypes); must list every symbol of include/kmunet_hip.h
 SIGNATURES = {
     "kmu_version": (_I, []),
@@ -164,6 +175,11 @@ SIGNATURES = {
     "kmu_lca_bwd": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "kmu_dagem_edges_fwd": (_I, [_P] * 2 + [_I] * 4 + [_P]),
     "kmu_dagem_edges_bwd": (_I, [_P] * 3 + [_I] * 4 + [_P]),
+    "kmu_dagem_args_bytes": (_Z, []),
+    "kmu_dagem_supported": (_I, [_I]),
+    "kmu_dagem_tiles": (_I, [_I] * 3),
+    "kmu_dagem_part_floats": (_Z, [_I] * 4),
+    "kmu_dagem_stage": (_I, [_P, _I, _P]),
     "kmu_triple_norm_supported": (_I, [_I, _I]),
     "kmu_triple_norm_splits": (_I, [_I]),
     "kmu_triple_norm_partials": (_I, [_I, _I, _I]),

@@ -39,6 +39,7 @@ SOURCES = [
     ("resize.hip", []),
     ("triple_norm.hip", []),
     ("dagem.hip", []),
+    ("dagem_fused.hip", []),
     ("ffn_fused.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

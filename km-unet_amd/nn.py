@@ -17,6 +17,9 @@ import os as _os
 # Debug only (tests/tools): comma list of fused glue ops to route back through stock PyTorch, e.g.
 # KMU_GLUE_TORCH=bn_blend,dwconv,conv1x1,qkv_gate -- used to bisect numerics; never set in production.
 _TORCH_GLUE = set(filter(None, _os.environ.get("KMU_GLUE_TORCH", "").split(",")))
+# DAGEM around its deformable convolution as one launch per BatchNorm boundary (csrc/dagem_fused.hip); False: the round-2 sequence of
+# pointwise-conv / BatchNorm / edge kernels (kept as the A/B partner of tests/test_gpu_kernels.py::test_dagem_fused_matches_unfused)
+_DAGEM_FUSED = True
 
 
 def conv1x1(x, conv, gelu_in=False):
@@ -484,6 +487,12 @@ class DAGEM(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
+        if x.is_cuda and "dagem" not in _TORCH_GLUE and _DAGEM_FUSED:
+            bns = [s_[1] for s_ in (self.edge_aggregation_func, self.vertex_update_func, self.edge_update_func,
+                                    self.update_edge_reduce_func)] + [self.final_aggregation_layer[1]]
+            if ops.dagem_supported(x, bns):
+                # one launch per BatchNorm boundary (csrc/dagem_fused.hip); the residual of :101 is added where the concatenation is read
+                return ops.dagem_glue(x, self.deform_conv(x, conv3x3(x, self.offset_conv)), self)
         if x.is_cuda and "dagem" not in _TORCH_GLUE:
             # same arithmetic, fewer launches: edge products by one gather kernel, Linear outputs kept channel-major so that
             # BatchNorm1d + ReLU run on the NCHW BatchNorm kernels

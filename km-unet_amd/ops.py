@@ -1520,6 +1520,115 @@ class DagemEdgesFn(torch.autograd.Function):
         return dx
 
 
+class DagemFn(torch.autograd.Function):
+    """DAGEM_md.py:56-111 minus the deformable convolution, one launch per BatchNorm boundary (csrc/dagem_fused.hip): 4 launches
+    forward, 5 + one column-sum launch backward.  forward(x, dconv, bns, training, wa, ba, wv, bv, we, be, wr, br, wf, gamma x 5,
+    beta x 5) -> out; dconv = deform_conv(x, offset_conv(x)) WITHOUT the residual (added in stage 2).  bns: the five BatchNorm modules in
+    the order edge_aggregation, vertex_update, edge_update, update_edge_reduce, final (running statistics updated in place)."""
+
+    NP = 19
+
+    @staticmethod
+    def _args(x, dconv, bns, training, params):
+        B, C, H, W = x.shape
+        a = _lib.DagemArgs()
+        a.B, a.C, a.H, a.W, a.training = B, C, H, W, int(training)
+        for i, bn in enumerate(bns):
+            a.eps[i], a.momentum[i] = float(bn.eps), float(bn.momentum)
+            a.gamma[i], a.beta[i] = _ptr(params[9 + i]), _ptr(params[14 + i])
+            a.running_mean[i], a.running_var[i] = _ptr(bn.running_mean), _ptr(bn.running_var)
+            a.num_batches_tracked[i] = _ptr(bn.num_batches_tracked) if training else None
+        a.x, a.dconv = _ptr(x), _ptr(dconv)
+        for name, t in zip(("wa", "ba", "wv", "bv", "we", "be", "wr", "br", "wf"), params[:9]):
+            setattr(a, name, _ptr(t))
+        return a
+
+    @staticmethod
+    def forward(ctx, x, dconv, bns, training, *params):
+        import ctypes
+        lib = _lib.load()
+        x, dconv = _f32c(x, "x"), _f32c(dconv, "deform_conv output")
+        params = tuple(_f32c(p, "DAGEM parameter") for p in params)
+        B, C, H, W = x.shape
+        P, C2, dev = H * W, C // 2, x.device
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        sv = dict(a_pre=mk(B, C, P), u_pre=mk(B, C2, P, 4), v_pre=mk(B, C2, P), r_pre=mk(B, C2, P), z=mk(B, C, P), bnstat=mk(5, C, 2),
+                  part=mk(lib.kmu_dagem_part_floats(B, C, H, W)))
+        out = mk(B, C, H, W)
+        a = DagemFn._args(x, dconv, bns, training, params)
+        for k, t in sv.items():
+            setattr(a, k, _ptr(t))
+        a.out = _ptr(out)
+        tap = None
+        if RELU_TAP is not None:
+            tap = dict(agg_out=mk(B, C, P), u_out=mk(B, C2, P, 4), vert_out=mk(B, C2, P), ue_out=mk(B, C2, P))
+            for k, t in tap.items():
+                setattr(a, k, _ptr(t))
+        st = _stream()
+        for stage in range(4):
+            _lib.check(_call(("dagem_fwd%d" % stage, (B, C, H, W)), lib.kmu_dagem_stage, ctypes.byref(a), stage, st), "kmu_dagem_stage")
+        if tap is not None:      # the five ReLU masks in the reference's call order and row layouts (DAGEM_md.py:65-104)
+            RELU_TAP.append((tap["agg_out"] > 0).reshape(-1, 1).cpu())
+            RELU_TAP.append((tap["vert_out"] > 0).permute(0, 2, 1).reshape(-1, C2).cpu())
+            RELU_TAP.append((tap["u_out"] > 0).permute(0, 2, 3, 1).reshape(-1, C2).cpu())
+            RELU_TAP.append((tap["ue_out"] > 0).reshape(-1, 1).cpu())
+            RELU_TAP.append((out.detach() > 0).cpu())
+        ctx.save_for_backward(x, dconv, *params, *sv.values())
+        ctx.sv_keys = tuple(sv)
+        ctx.bns, ctx.training = bns, training
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.defer = _leaf(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        lib = _lib.load()
+        t = ctx.saved_tensors
+        x, dconv, params = t[0], t[1], t[2:2 + DagemFn.NP]
+        sv = dict(zip(ctx.sv_keys, t[2 + DagemFn.NP:]))
+        g = _f32c(g, "grad")
+        B, C, H, W = x.shape
+        P, C2, dev = H * W, C // 2, x.device
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        a = DagemFn._args(x, dconv, ctx.bns, ctx.training, params)
+        for k, v in sv.items():
+            setattr(a, k, _ptr(v))
+        NW = lib.kmu_dagem_tiles(B, H, W)
+        sc = dict(part_bwd=mk(lib.kmu_dagem_part_floats(B, C, H, W)), g_dd=mk(B, C, H, W), gv=mk(B, C2, P), gr=mk(B, C2, P), ga=mk(B, C, P),
+                  dr_pre=mk(B, C2, P), dxb=mk(B, C, P), de=mk(B, C, P, 4), dx=mk(B, C, H, W), p_wf=mk(NW, C, C + C2), p_wv=mk(NW, C2, 2 * C),
+                  p_bv=mk(NW, C2), p_we=mk(NW, C2, 2 * C), p_be=mk(NW, C2), p_wa=mk(NW, 5), p_wr=mk(NW, 5))
+        for k, v in sc.items():
+            setattr(a, k, _ptr(v))
+        a.g_out = _ptr(g)
+        dg, db = [mk(*ctx.shapes[9 + i]) for i in range(5)], [mk(*ctx.shapes[14 + i]) for i in range(5)]
+        for i in range(5):
+            a.d_gamma[i], a.d_beta[i] = _ptr(dg[i]), _ptr(db[i])
+        st = _stream()
+        for stage in range(4, 9):
+            _lib.check(_call(("dagem_bwd%d" % (stage - 4), (B, C, H, W)), lib.kmu_dagem_stage, ctypes.byref(a), stage, st), "kmu_dagem_stage")
+        dwa, dba, dwv, dbv, dwe, dbe, dwr, dbr, dwf = [mk(*ctx.shapes[i]) for i in range(9)]
+        pa, pr = sc["p_wa"], sc["p_wr"]
+        _wgrad(lambda: colsum(sc["p_wf"], sc["p_wv"], sc["p_bv"], sc["p_we"], sc["p_be"], pa[:, :4], pa[:, 4:], pr[:, :4], pr[:, 4:],
+                              outs=[dwf, dwv, dbv, dwe, dbe, dwa, dba, dwr, dbr]), ctx.defer)
+        return (sc["dx"], sc["g_dd"], None, None, dwa, dba, dwv, dbv, dwe, dbe, dwr, dbr, dwf, *dg, *db)
+
+
+def dagem_supported(x, bns):
+    return (x.is_cuda and x.dim() == 4 and bool(_lib.load().kmu_dagem_supported(x.shape[1]))
+            and all(bn.momentum is not None and bn.track_running_stats and bn.affine for bn in bns))
+
+
+def dagem_glue(x, dconv, mod):
+    """Everything of DAGEM.forward (DAGEM_md.py:56-111) around the deformable convolution: out = final(cat(dconv + x, vertex * edge))."""
+    seqs = (mod.edge_aggregation_func, mod.vertex_update_func, mod.edge_update_func, mod.update_edge_reduce_func)
+    bns = [s_[1] for s_ in seqs] + [mod.final_aggregation_layer[1]]
+    lin = {k: s_[0] for k, s_ in zip("aver", seqs)}
+    params = (lin["a"].weight, lin["a"].bias, lin["v"].weight, lin["v"].bias, lin["e"].weight, lin["e"].bias, lin["r"].weight, lin["r"].bias,
+              mod.final_aggregation_layer[0].weight, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+    return DagemFn.apply(x, dconv, bns, mod.training, *params)
+
+
 def dagem_edges(x):
     return DagemEdgesFn.apply(x)
 

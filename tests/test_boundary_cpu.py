@@ -33,6 +33,8 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.kmu_version() == 1
+    import ctypes
+    assert lib.kmu_dagem_args_bytes() == ctypes.sizeof(_l.DagemArgs)       # the ctypes mirror of struct kmu_dagem_args
     # size queries are pure host arithmetic and may be called without a GPU
     assert lib.kmu_kan_pack_fwd_elems(16, 16) == 4 * 81 * 1 * 64
     assert lib.kmu_kan_pack_bwd_elems(64, 32) == 8 * 81 * 4 * 64

@@ -1201,6 +1201,48 @@ def test_dagem_block_golden_with_plain_conv_stand_in(name, train):
     _report(name, **errs)
 
 
+@pytest.mark.parametrize("B,C,H,W,train", [(8, 64, 16, 16, True), (2, 64, 16, 16, False), (3, 32, 7, 9, True), (1, 64, 32, 32, True),
+                                            (2, 32, 5, 4, False)])
+def test_dagem_fused_matches_unfused(B, C, H, W, train):
+    """csrc/dagem_fused.hip (one launch per BatchNorm boundary) against the round-2 sequence of pointwise-conv / BatchNorm / edge kernels
+    (nn._DAGEM_FUSED = False) on the same module: output, input gradient, every parameter gradient, the running statistics and the batch
+    counters -- bench shape, ragged pixel counts (partial 32-pixel tiles), C = 32, train and eval mode."""
+    import copy
+    import km_unet_amd
+    from km_unet_amd import nn as KN
+    from oracle.model import fill_parameters
+    torch.manual_seed(B * 100 + H)
+    base = fill_parameters(km_unet_amd.DAGEM(sync_bn=False, input_channels=C), 5).to(DEV)
+    x0 = torch.randn(B, C, H, W, device=DEV)
+    gy = torch.randn(B, C, H, W, device=DEV)
+    res = {}
+    saved = KN._DAGEM_FUSED
+    try:
+        for fused in (True, False):
+            KN._DAGEM_FUSED = fused
+            m = copy.deepcopy(base).train(train)
+            x = x0.clone().requires_grad_(True)
+            y = m(x)
+            y.backward(gy)
+            res[fused] = (y.detach(), x.grad, {k: p.grad for k, p in m.named_parameters()}, {k: b.clone() for k, b in m.named_buffers()})
+    finally:
+        KN._DAGEM_FUSED = saved
+    errs = {"y": rel_err(res[True][0], res[False][0]), "dx": rel_err(res[True][1], res[False][1])}
+    gmax = max(v.abs().max().item() for v in res[False][2].values() if v is not None)
+    for k, ref in res[False][2].items():
+        got = res[True][2][k]
+        assert (got is None) == (ref is None), k
+        if ref is not None:      # (a bias in front of a batch-statistics BatchNorm has an exactly-zero gradient: rounding noise on both sides)
+            errs["d_" + k] = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-4 * gmax)
+    for k, ref in res[False][3].items():
+        got = res[True][3][k]
+        if ref.dtype == torch.long:
+            assert torch.equal(got, ref), k
+        else:
+            errs["buf_" + k] = rel_err(got, ref)
+    _report("dagem fused %s train=%s" % ((B, C, H, W), train), **errs)
+
+
 @pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(8, 16, 64, 64, 32, 32), (8, 32, 32, 32, 64, 64), (2, 5, 7, 9, 13, 4), (1, 3, 16, 16, 1, 1),
                                              (1, 2, 1, 5, 6, 5), (2, 16, 128, 128, 64, 64), (1, 4, 30, 30, 60, 60)])
 def test_resize_bilinear_vs_torch_cpu(B, C, Hi, Wi, Ho, Wo):
