@@ -73,11 +73,23 @@ __device__ __forceinline__ void fold_pairs(const float* __restrict__ part, int s
         for (int f0 = 0; f0 < NF; f0 += 32) {
             const int f = f0 + (tid >> 3);
             double a = 0.0, q = 0.0;
-            if (f < NF)
-                for (int i = j; i < NWG; i += 8) {
+            if (f < NF) {
+                int i = j;
+                for (; i + 24 < NWG; i += 32) {          // four independent loads in flight, summed in index order
+                    const float2 v0 = *reinterpret_cast<const float2*>(part + (size_t)i * stride + 2 * f);
+                    const float2 v1 = *reinterpret_cast<const float2*>(part + (size_t)(i + 8) * stride + 2 * f);
+                    const float2 v2 = *reinterpret_cast<const float2*>(part + (size_t)(i + 16) * stride + 2 * f);
+                    const float2 v3 = *reinterpret_cast<const float2*>(part + (size_t)(i + 24) * stride + 2 * f);
+                    a += (double)v0.x, q += (double)v0.y;
+                    a += (double)v1.x, q += (double)v1.y;
+                    a += (double)v2.x, q += (double)v2.y;
+                    a += (double)v3.x, q += (double)v3.y;
+                }
+                for (; i < NWG; i += 8) {
                     a += (double)part[(size_t)i * stride + 2 * f];
                     q += (double)part[(size_t)i * stride + 2 * f + 1];
                 }
+            }
 #pragma unroll
             for (int m = 4; m > 0; m >>= 1) {
                 a += shfl_xor_d(a, m);
@@ -186,35 +198,88 @@ __device__ __forceinline__ Tile tile_of(const kmu_dagem_args& a) {
     t.wg = blockIdx.x;
     return t;
 }
+// The loaders below issue LB global loads before the first LDS store: a plain load -> store loop waits out one memory round trip per
+// iteration (the first version of these kernels spent 15 of their 20 us there).
+constexpr int LB = 8;
 // dst[c][32] <- src[b][c][gp0 + p] (zeros past the sample's last pixel)
 __device__ __forceinline__ void load_tile(float* dst, const float* __restrict__ src, int nch, int P, const Tile& t) {
     const float* s = src + (size_t)t.b * nch * P + t.gp0;
-    for (int i = threadIdx.x; i < nch * TP; i += 256) {
-        const int c = i >> 5, p = i & 31;
-        dst[i] = p < t.np ? s[(size_t)c * P + p] : 0.f;
+    const int n = nch * TP;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * LB) {
+        float v[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int i = i0 + u * 256, c = i >> 5, p = i & 31;
+            v[u] = (i < n && p < t.np) ? s[(size_t)c * P + p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            if (i0 + u * 256 < n) dst[i0 + u * 256] = v[u];
     }
 }
 // the pixel's own value and its four cyclic neighbours (DAGEM_md.py:57-60: rows -1 / +1, columns -1 / +1): xs[k5][c][32]
 __device__ __forceinline__ void load_tile5(float* xs, const float* __restrict__ x, int C, int H, int W, const Tile& t) {
-    const int P = H * W;
+    const int P = H * W, p = threadIdx.x & 31;
     const float* s = x + (size_t)t.b * C * P;
-    for (int i = threadIdx.x; i < 5 * C * TP; i += 256) {
-        const int p = i & 31, c = (i >> 5) % C, k = i / (C * TP);
-        float v = 0.f;
-        if (p < t.np) {
-            const int g = t.gp0 + p, h = g / W, w = g - h * W;
-            int q = g;
-            if (k == 1) q = (h == 0 ? H - 1 : h - 1) * W + w;
-            else if (k == 2) q = (h == H - 1 ? 0 : h + 1) * W + w;
-            else if (k == 3) q = h * W + (w == 0 ? W - 1 : w - 1);
-            else if (k == 4) q = h * W + (w == W - 1 ? 0 : w + 1);
-            v = s[(size_t)c * P + q];
+    int q[5];
+    {
+        const int g = min(t.gp0 + p, P - 1), h = g / W, w = g - h * W;
+        q[0] = g;
+        q[1] = (h == 0 ? H - 1 : h - 1) * W + w;
+        q[2] = (h == H - 1 ? 0 : h + 1) * W + w;
+        q[3] = h * W + (w == 0 ? W - 1 : w - 1);
+        q[4] = h * W + (w == W - 1 ? 0 : w + 1);
+    }
+    const bool ok = p < t.np;
+    // thread = (pixel p, channel phase tid >> 5): channels c = (tid >> 5) + 8 j, all five positions of LB / ... channels in flight
+    for (int c0 = threadIdx.x >> 5; c0 < C; c0 += 8 * 2) {
+        float v[2][5];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c = c0 + 8 * u;
+                v[u][k] = (ok && c < C) ? s[(size_t)c * P + q[k]] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c = c0 + 8 * u;
+                if (c < C) xs[(k * C + c) * TP + p] = v[u][k];
+            }
+    }
+}
+// dst[c][p] = op(c, p, {src_0[b][c][pixel], ..}) over an nch-channel tile, the loads of four elements in flight before the first use
+template <int NS, class OP>
+__device__ __forceinline__ void tile_apply(float* dst, int nch, int P, const Tile& t, const float* const (&src)[NS], OP op) {
+    constexpr int UB = 4;
+    const int n = nch * TP;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * UB) {
+        float v[UB][NS];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + u * 256, c = i >> 5, p = i & 31;
+            const bool ok = i < n && p < t.np;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) v[u][k] = ok ? src[k][((size_t)t.b * nch + c) * P + t.gp0 + p] : 0.f;
         }
-        xs[i] = v;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + u * 256;
+            if (i < n) dst[i] = (i & 31) < t.np ? op(i >> 5, i & 31, v[u]) : 0.f;
+        }
     }
 }
 __device__ __forceinline__ void load_vec(float* dst, const float* __restrict__ src, int n) {
-    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * LB) {
+        float v[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) v[u] = i0 + u * 256 < n ? src[i0 + u * 256] : 0.f;
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            if (i0 + u * 256 < n) dst[i0 + u * 256] = v[u];
+    }
 }
 
 // ===================================================================================================================== forward
@@ -261,6 +326,7 @@ __global__ __launch_bounds__(256) void dagem_f0(kmu_dagem_args a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) u[j][k] = 0.f;
         }
+#pragma unroll 2
         for (int c = 0; c < C; ++c) {
             const float x0 = xs[c * TP + p];
             float e[4];
@@ -315,13 +381,12 @@ __global__ __launch_bounds__(256) void dagem_f1(kmu_dagem_args a, int NWG) {
     load_vec(wv, a.wv, C2 * 2 * C);
     {
         const float s = scA[0], h = scA[1];
-        const float* ap = a.a_pre + (size_t)t.b * C * P + t.gp0;
-        for (int i = tid; i < C * TP; i += 256) {
-            const int c = i >> 5, p = i & 31;
-            const float v = p < t.np ? relu_bn(ap[(size_t)c * P + p], s, h) : 0.f;
-            ag[i] = v;
-            if (a.agg_out && p < t.np) a.agg_out[((size_t)t.b * C + c) * P + t.gp0 + p] = v;
-        }
+        const float* const src[1] = {a.a_pre};
+        tile_apply<1>(ag, C, P, t, src, [&](int c, int p, const float (&v)[1]) {
+            const float r = relu_bn(v[0], s, h);
+            if (a.agg_out) a.agg_out[((size_t)t.b * C + c) * P + t.gp0 + p] = r;
+            return r;
+        });
     }
     __syncthreads();
     float* part = a.part + t.wg * part_stride(C);
@@ -331,6 +396,7 @@ __global__ __launch_bounds__(256) void dagem_f1(kmu_dagem_args a, int NWG) {
         float acc[OPT];
 #pragma unroll
         for (int j = 0; j < OPT; ++j) acc[j] = a.bv[g * OPT + j];
+#pragma unroll 2
         for (int c = 0; c < C; ++c) {
             const float x0 = xs[c * TP + p], a0 = ag[c * TP + p];
 #pragma unroll
@@ -396,25 +462,17 @@ __global__ __launch_bounds__(256) void dagem_f2(kmu_dagem_args a, int NWG) {
     bn_coeffs<1>(a, BN_R, a.part, NWG, (double)a.B * C2 * P, writer, scR, scR + 1, tmp, red);
     load_vec(wf, a.wf, C * KF);
     {
-        const float* xp = a.x + (size_t)t.b * C * P + t.gp0;
-        const float* dp = a.dconv + (size_t)t.b * C * P + t.gp0;
-        for (int i = tid; i < C * TP; i += 256) {
-            const int c = i >> 5, p = i & 31;
-            in[i] = p < t.np ? dp[(size_t)c * P + p] + xp[(size_t)c * P + p] : 0.f;
-        }
+        const float* const s2[2] = {a.dconv, a.x};
+        tile_apply<2>(in, C, P, t, s2, [](int, int, const float (&v)[2]) { return v[0] + v[1]; });
         const float sr = scR[0], hr = scR[1];
-        for (int i = tid; i < C2 * TP; i += 256) {
-            const int o = i >> 5, p = i & 31;
-            float v = 0.f;
-            if (p < t.np) {
-                const size_t idx = ((size_t)t.b * C2 + o) * P + t.gp0 + p;
-                const float vert = relu_bn(a.v_pre[idx], scV[o], shV[o]), ue = relu_bn(a.r_pre[idx], sr, hr);
-                if (a.vert_out) a.vert_out[idx] = vert;
-                if (a.ue_out) a.ue_out[idx] = ue;
-                v = vert * ue;
-            }
-            in[C * TP + i] = v;
-        }
+        const float* const s3[2] = {a.v_pre, a.r_pre};
+        tile_apply<2>(in + C * TP, C2, P, t, s3, [&](int o, int p, const float (&v)[2]) {
+            const float vert = relu_bn(v[0], scV[o], shV[o]), ue = relu_bn(v[1], sr, hr);
+            const size_t idx = ((size_t)t.b * C2 + o) * P + t.gp0 + p;
+            if (a.vert_out) a.vert_out[idx] = vert;
+            if (a.ue_out) a.ue_out[idx] = ue;
+            return vert * ue;
+        });
     }
     __syncthreads();
     float* part = a.part + t.wg * part_stride(C);
@@ -423,6 +481,7 @@ __global__ __launch_bounds__(256) void dagem_f2(kmu_dagem_args a, int NWG) {
     float acc[OPT];
 #pragma unroll
     for (int j = 0; j < OPT; ++j) acc[j] = 0.f;
+#pragma unroll 2
     for (int k = 0; k < KF; ++k) {
         const float v = in[k * TP + p];
 #pragma unroll
@@ -511,18 +570,14 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
     const bool writer = blockIdx.x == 0;
     bn_bwd_coeffs<C>(a, BN_F, a.part_bwd, NWG, (double)a.B * P, writer, m1, m2, mean, rstd, sc, sh, tmp, red);
     load_vec(wf, a.wf, C * KF);
-    for (int i = tid; i < C * TP; i += 256) {
-        const int c = i >> 5, p = i & 31;
-        float v = 0.f, d = 0.f;
-        if (p < t.np) {
-            const size_t idx = ((size_t)t.b * C + c) * P + t.gp0 + p;
-            const float zv = a.z[idx];
-            const float gp = relu_bn(zv, sc[c], sh[c]) > 0.f ? a.g_out[idx] : 0.f;
-            v = sc[c] * (gp - m1[c] - ((zv - mean[c]) * rstd[c]) * m2[c]);
-            d = a.dconv[idx] + a.x[idx];
-        }
-        dz[i] = v;
-        in[i] = d;
+    {
+        const float* const s2[2] = {a.dconv, a.x};
+        tile_apply<2>(in, C, P, t, s2, [](int, int, const float (&v)[2]) { return v[0] + v[1]; });
+        const float* const s3[2] = {a.z, a.g_out};
+        tile_apply<2>(dz, C, P, t, s3, [&](int c, int, const float (&v)[2]) {
+            const float gp = relu_bn(v[0], sc[c], sh[c]) > 0.f ? v[1] : 0.f;
+            return sc[c] * (gp - m1[c] - ((v[0] - mean[c]) * rstd[c]) * m2[c]);
+        });
     }
     // vert / ue of this tile (registers of the threads that own (o, p) below) and f into `in`
     const int p = tid & 31, g = tid >> 5;
@@ -555,6 +610,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
         float acc[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+#pragma unroll 2
         for (int o = 0; o < C; ++o) {
             const float d = dz[o * TP + p];
 #pragma unroll
@@ -570,6 +626,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
         float df[OPT];
 #pragma unroll
         for (int j = 0; j < OPT; ++j) df[j] = 0.f;
+#pragma unroll 2
         for (int o = 0; o < C; ++o) {
             const float d = dz[o * TP + p];
 #pragma unroll
@@ -608,6 +665,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
         float acc[IPT];
 #pragma unroll
         for (int i = 0; i < IPT; ++i) acc[i] = 0.f;
+#pragma unroll 2
         for (int q = 0; q < TP; ++q) {
             const float d = dz[o * TP + q];
 #pragma unroll
@@ -642,20 +700,12 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
     const float muA = a.bnstat[(BN_A * C) * 2], rsA = a.bnstat[(BN_A * C) * 2 + 1];
     const float scA = a.gamma[BN_A][0] * rsA, shA = a.beta[BN_A][0] - muA * scA;
     {
-        const float* ap = a.a_pre + (size_t)t.b * C * P + t.gp0;
-        for (int i = tid; i < C * TP; i += 256) {
-            const int c = i >> 5, p = i & 31;
-            in[C * TP + i] = p < t.np ? relu_bn(ap[(size_t)c * P + p], scA, shA) : 0.f;
-        }
-        for (int i = tid; i < C2 * TP; i += 256) {
-            const int o = i >> 5, p = i & 31;
-            float v = 0.f;
-            if (p < t.np) {
-                const size_t idx = ((size_t)t.b * C2 + o) * P + t.gp0 + p;
-                v = sc[o] * (a.gv[idx] - m1[o] - ((a.v_pre[idx] - mean[o]) * rstd[o]) * m2[o]);
-            }
-            dv[i] = v;
-        }
+        const float* const s1[1] = {a.a_pre};
+        tile_apply<1>(in + C * TP, C, P, t, s1, [&](int, int, const float (&v)[1]) { return relu_bn(v[0], scA, shA); });
+        const float* const s2[2] = {a.gv, a.v_pre};
+        tile_apply<2>(dv, C2, P, t, s2, [&](int o, int, const float (&v)[2]) {
+            return sc[o] * (v[0] - m1[o] - ((v[1] - mean[o]) * rstd[o]) * m2[o]);
+        });
     }
     __syncthreads();
     float* part = a.part_bwd + t.wg * part_stride(C);
@@ -666,6 +716,7 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
         float ax[CPT], ag[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) ax[j] = ag[j] = 0.f;
+#pragma unroll 2
         for (int o = 0; o < C2; ++o) {
             const float d = dv[o * TP + p];
 #pragma unroll
@@ -674,7 +725,9 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
                 ag[j] += wv[o * 2 * C + C + g * CPT + j] * d;
             }
         }
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, apre[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) apre[j] = ok ? a.a_pre[((size_t)t.b * C + g * CPT + j) * P + t.gp0 + p] : 0.f;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = g * CPT + j;
@@ -684,7 +737,7 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
                 a.dxb[idx] = ax[j];
                 a.ga[idx] = gav;
                 s1 += gav;
-                s2 += gav * ((a.a_pre[idx] - muA) * rsA);
+                s2 += gav * ((apre[j] - muA) * rsA);
             }
         }
         block_sum2(s1, s2, red8);
@@ -699,6 +752,7 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
         float acc[IPT], sb = 0.f;
 #pragma unroll
         for (int i = 0; i < IPT; ++i) acc[i] = 0.f;
+#pragma unroll 2
         for (int q = 0; q < TP; ++q) {
             const float d = dv[o * TP + q];
             sb += d;
@@ -802,11 +856,21 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
         const float mA1 = ca[0], mA2 = ca[1], muA = ca[2], rsA = ca[3], scA = ca[4];
         const float wa0 = a.wa[0], wa1 = a.wa[1], wa2 = a.wa[2], wa3 = a.wa[3];
         float was[4] = {0.f, 0.f, 0.f, 0.f}, bas = 0.f;
+        float gav[CPT], apre[CPT], dxv[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const size_t idx = ((size_t)t.b * C + g * CPT + j) * P + t.gp0 + p;
+            gav[j] = ok ? a.ga[idx] : 0.f;
+            apre[j] = ok ? a.a_pre[idx] : 0.f;
+            dxv[j] = ok ? a.dxb[idx] : 0.f;
+        }
+#pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = g * CPT + j;
             floatx4 de = {0.f, 0.f, 0.f, 0.f};
             float dx = 0.f;
-            for (int o = 0; o < C2; ++o) {
+    #pragma unroll 2
+        for (int o = 0; o < C2; ++o) {
                 const floatx4 d = *reinterpret_cast<const floatx4*>(du + (o * TP + p) * 4);
                 const float w2 = we[o * 2 * C + C + c];
                 de += w2 * d;
@@ -814,7 +878,7 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
             }
             if (ok) {
                 const size_t idx = ((size_t)t.b * C + c) * P + t.gp0 + p;
-                const float da = scA * (a.ga[idx] - mA1 - ((a.a_pre[idx] - muA) * rsA) * mA2);
+                const float da = scA * (gav[j] - mA1 - ((apre[j] - muA) * rsA) * mA2);
                 const float x0 = xs[c * TP + p];
                 const float e0 = x0 * xs[(C + c) * TP + p], e1 = x0 * xs[(2 * C + c) * TP + p], e2 = x0 * xs[(3 * C + c) * TP + p],
                             e3 = x0 * xs[(4 * C + c) * TP + p];
@@ -822,7 +886,7 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
                 bas += da;
                 de += floatx4{wa0 * da, wa1 * da, wa2 * da, wa3 * da};
                 *reinterpret_cast<floatx4*>(a.de + idx * 4) = de;
-                a.dxb[idx] += dx;
+                a.dxb[idx] = dxv[j] + dx;
             }
         }
         block_sum2(was[0], was[1], red8);
@@ -840,6 +904,7 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
         float ax[IPT], ae[IPT], sb = 0.f;
 #pragma unroll
         for (int i = 0; i < IPT; ++i) ax[i] = ae[i] = 0.f;
+#pragma unroll 2
         for (int q = 0; q < TP; ++q) {
             const floatx4 d = *reinterpret_cast<const floatx4*>(du + (o * TP + q) * 4);
             const float ds = (d[0] + d[1]) + (d[2] + d[3]);
