@@ -55,14 +55,15 @@ RIDGE = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # FLOP/B at which f
 
 
 def pmc_traffic(name, shape):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r04a_pmc_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r04b_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), measured at the bench shape only; None for
     kernels / shapes without a PMC pass."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r04a_pmc_traffic.json")))["kernels"]
+        table = json.load(open(os.path.join(ROOT, "profiles", "r04b_pmc_traffic.json")))["kernels"]
     except Exception:
         return None
-    key = {("hsmssd_bwd_passB", (8, 16, 128)): "hsm_bwd_passB<16>", ("hsmssd_bwd_passA_x3", (8, 16, 128)): "hsm_bwd_passA_x3<16>",
+    key = {("mixer_bwd_passB", (8, 16, 128)): "hsm_bwd_passB<16>", ("mixer_bwd_corr", (8, 16, 128)): "hsm_bwd_corr<16>",
+           ("hsmssd_bwd_passB", (8, 32, 64)): "hsm_bwd_passB<32>", ("hsmssd_bwd_passA_x3", (8, 32, 64)): "hsm_bwd_passA_x3<32>",
            ("hsmssd_fwd_pass1_v2", (8, 16, 128)): "hsm2_fwd_pass1<16, 4, 8, true>", ("hsmssd_fwd_pass2_v2", (8, 16, 128)): "hsm2_fwd_pass2<16>",
            ("hsmssd_fwd_pass1_v2", (8, 32, 64)): "hsm2_fwd_pass1<32, 1, 8, false>", ("hsmssd_fwd_pass2_v2", (8, 32, 64)): "hsm2_fwd_pass2<32>",
            ("kan_conv2d_fwd_x3", (8, 16, 16, 128, 128)): "conv3x3_x3_fwd_kernel<0, 3, 8, 32, 4, 1, 1>",

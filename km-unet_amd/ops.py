@@ -772,15 +772,17 @@ def _hsmssd_backward(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_
 
 
 _MIXER_BWD_STAGES = ("mixer_bwd_corr", "mixer_bwd_crows", "hsmssd_bwd_gate", "mixer_bwd_passB")
-# Widest channel count whose backward takes the C rows as a per-sample dense convolution (csrc/hsmssd_bwdc.inc).  G = dy (*) x is
-# 9 C^2 floats per partial against pass A's 64 C, and the C chunks are pass B's cheapest: measured alone (tools/time_k2_bwd.py,
-# profiles/r04_k2_backward_times.json) the whole backward goes 173 -> 147 us at C = 16, 105 -> 105 at C = 32 (one launch more) and
-# 292 -> 305 at C = 64 -- so only the 16-channel level takes this route; every C is instantiated and tested on both.
-MIXER_BWD_CROWS_MAXC = 16
+# Channel counts whose backward takes the C rows as a per-sample dense convolution (csrc/hsmssd_bwdc.inc).  Measured alone
+# (tools/time_k2_bwd.py, profiles/r04_k2_backward_times.json), whole backward per mixer: C = 16 (8 x 128 x 128) 173 -> 146 us (four
+# cheap chunks of pass B and the pass-A recompute go); C = 64 (24 x 32 x 32) 291 -> 254 us (pass B no longer keeps the dy image beside
+# x: 108 -> 80 KB of LDS = two workgroups per CU, 221 -> 174 us; G = dy (*) x costs 9 C^2 floats per partial there, 28 MB of slabs);
+# C = 32 (8 x 64 x 64) 105 -> 105 us with one launch more (256 tiles = one workgroup per CU either way) -- that level keeps pass A /
+# pass B on all rows.  Every C is instantiated and tested on both routes.
+MIXER_BWD_CROWS = (16, 64)
 
 
 def _mixer_backward(xn, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_ok, groups=1, tag=""):
-    """Backward behind MixerFn's forward given the (normalised) input, the saved gate state and dy / dh.  C <= MIXER_BWD_CROWS_MAXC:
+    """Backward behind MixerFn's forward given the (normalised) input, the saved gate state and dy / dh.  C in MIXER_BWD_CROWS:
     the C rows as a per-sample dense convolution with the M_b the forward left in `state` (correlation G = dy (*) x, the C rows'
     contractions of G, the gate stage, pass B on the {B, dt} rows); else pass A, gate, pass B on all rows.
     -> dx, (column-sum inputs, rows of w_bcdt / w_dw they belong to): see _mixer_colsums."""
@@ -796,7 +798,7 @@ def _mixer_backward(xn, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_
     p_bcdt, p_dw = mk(P, 3 * N, C), mk(P, 3 * N, 9)
     p_hz, p_out, p_D = mk(Gp, 2 * C, C), mk(Gp, C, C), mk(Gp)
     st = _stream()
-    if C > MIXER_BWD_CROWS_MAXC:
+    if C not in MIXER_BWD_CROWS:
         nbytes = lib.kmu_hsmssd_bwd_ws_bytes_x3_g(B, C, N, Hs, groups)
         ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
         wpk = _hsm_pack(pack_ok, w_bcdt, w_dw, C, st, groups)

@@ -264,7 +264,7 @@ def test_mixer_ln_vs_oracle(B, C, Hs, rows):
 
 @pytest.mark.parametrize("B,C,Hs", [(2, 16, 40), (3, 32, 17), (2, 64, 16), (8, 16, 128)])
 def test_mixer_backward_crows_as_dense_conv_matches_row_kernels(B, C, Hs):
-    """The two backward routes behind MixerFn (ops.MIXER_BWD_CROWS_MAXC): the C rows as a per-sample dense convolution
+    """The two backward routes behind MixerFn (ops.MIXER_BWD_CROWS): the C rows as a per-sample dense convolution
     (csrc/hsmssd_bwdc.inc) and pass A / pass B on all 192 rows -- every C on both routes, against the fp32 oracle and against each other."""
     from oracle import hsmssd as oh
     ops = _ops()
@@ -282,10 +282,10 @@ def test_mixer_backward_crows_as_dense_conv_matches_row_kernels(B, C, Hs):
     yo, ho = oh.hsmssd(xn, *w.values(), state_dim=N)
     ((yo * gy).sum() + (ho * gh).sum()).backward()
     ref = dict({k: v.grad for k, v in dict(w, lw=lw, lb=lb).items() if k != "A"}, x=x.grad)
-    saved, got = ops.MIXER_BWD_CROWS_MAXC, {}
+    saved, got = ops.MIXER_BWD_CROWS, {}
     try:
         for mode in (64, 0):
-            ops.MIXER_BWD_CROWS_MAXC = mode
+            ops.MIXER_BWD_CROWS = (16, 32, 64) if mode else ()
             xd = x.detach().to(DEV).requires_grad_(True)
             pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in dict(w, lw=lw, lb=lb).items()}
             y, h = ops.mixer_ln(xd, pd["lw"], pd["lb"], 1e-5, *[pd[k] for k in w])
@@ -294,7 +294,7 @@ def test_mixer_backward_crows_as_dense_conv_matches_row_kernels(B, C, Hs):
             _report("mixer backward %s, C rows %s" % ((B, C, Hs), "as a dense conv" if mode else "in pass A / pass B"),
                     **{"d_" + k: rel_err(got[mode][k], ref[k]) for k in ref})
     finally:
-        ops.MIXER_BWD_CROWS_MAXC = saved
+        ops.MIXER_BWD_CROWS = saved
     errs = {k: rel_err(got[64][k], got[0][k]) for k in ref}
     assert max(errs.values()) < 1e-4, errs
 

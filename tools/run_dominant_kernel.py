@@ -36,8 +36,11 @@ for (Bm, Cm, Hm) in ((8, 16, 128), (8, 32, 64), (24, 64, 32)):
     lw, lb = torch.ones(Cm, device=d, requires_grad=True), torch.zeros(Cm, device=d, requires_grad=True)
     wm = [torch.randn(3 * N, Cm, 1, device=d) / Cm ** 0.5, torch.randn(3 * N, 1, 3, 3, device=d) * 0.3, torch.randn(2 * Cm, Cm, 1, device=d) / Cm ** 0.5,
           torch.randn(Cm, Cm, 1, device=d) / Cm ** 0.5, torch.ones(N, device=d), torch.ones(1, device=d)]
+    wm = [t.requires_grad_(True) for t in wm]
+    gm = torch.randn(Bm, Cm, Hm, Hm, device=d)
     for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         ym, hm = ops.mixer_ln(xm, lw, lb, 1e-5, *wm)
+        ym.backward(gm)          # C = 16: correlation, C-row contractions, gate, pass B on the {B, dt} rows; C >= 32: pass A, gate, pass B
 torch.cuda.synchronize()
 print("mixer done")
 
