@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void dagem_f0(kmu_dagem_args a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) u[j][k] = 0.f;
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int c = 0; c < C; ++c) {
             const float x0 = xs[c * TP + p];
             float e[4];
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void dagem_f1(kmu_dagem_args a, int NWG) {
         float acc[OPT];
 #pragma unroll
         for (int j = 0; j < OPT; ++j) acc[j] = a.bv[g * OPT + j];
-#pragma unroll 2
+#pragma unroll 4
         for (int c = 0; c < C; ++c) {
             const float x0 = xs[c * TP + p], a0 = ag[c * TP + p];
 #pragma unroll
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void dagem_f2(kmu_dagem_args a, int NWG) {
     float acc[OPT];
 #pragma unroll
     for (int j = 0; j < OPT; ++j) acc[j] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
     for (int k = 0; k < KF; ++k) {
         const float v = in[k * TP + p];
 #pragma unroll
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
         float acc[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int o = 0; o < C; ++o) {
             const float d = dz[o * TP + p];
 #pragma unroll
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
         float df[OPT];
 #pragma unroll
         for (int j = 0; j < OPT; ++j) df[j] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int o = 0; o < C; ++o) {
             const float d = dz[o * TP + p];
 #pragma unroll
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
         float acc[IPT];
 #pragma unroll
         for (int i = 0; i < IPT; ++i) acc[i] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int q = 0; q < TP; ++q) {
             const float d = dz[o * TP + q];
 #pragma unroll
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
         float ax[CPT], ag[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) ax[j] = ag[j] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int o = 0; o < C2; ++o) {
             const float d = dv[o * TP + p];
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
         float acc[IPT], sb = 0.f;
 #pragma unroll
         for (int i = 0; i < IPT; ++i) acc[i] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int q = 0; q < TP; ++q) {
             const float d = dv[o * TP + q];
             sb += d;
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
             const int c = g * CPT + j;
             floatx4 de = {0.f, 0.f, 0.f, 0.f};
             float dx = 0.f;
-    #pragma unroll 2
+    #pragma unroll 4
         for (int o = 0; o < C2; ++o) {
                 const floatx4 d = *reinterpret_cast<const floatx4*>(du + (o * TP + p) * 4);
                 const float w2 = we[o * 2 * C + C + c];
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
         float ax[IPT], ae[IPT], sb = 0.f;
 #pragma unroll
         for (int i = 0; i < IPT; ++i) ax[i] = ae[i] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int q = 0; q < TP; ++q) {
             const floatx4 d = *reinterpret_cast<const floatx4*>(du + (o * TP + q) * 4);
             const float ds = (d[0] + d[1]) + (d[2] + d[3]);

@@ -161,14 +161,14 @@ def _cs_desc(p, o):
     return p.shape[0] * p.shape[1], cols, (int(p.stride(1)) if p.shape[1] > 1 else cols), p.shape[1], int(p.stride(0))
 
 
-def _cs_launch(pairs, st):
+def _cs_args(pairs):
+    """ctypes argument block of kmu_colsum_multi_strided for (partial, result) pairs (built before the launch is timed)."""
     import ctypes
     n = len(pairs)
     vp, ip, lp = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
     d = [_cs_desc(p, o) for p, o in pairs]
-    return _lib.load().kmu_colsum_multi_strided(n, vp(*[p.data_ptr() for p, _ in pairs]), vp(*[o.data_ptr() for _, o in pairs]),
-                                                ip(*[x[0] for x in d]), ip(*[x[1] for x in d]), ip(*[x[2] for x in d]),
-                                                ip(*[x[3] for x in d]), lp(*[x[4] for x in d]), st)
+    return (n, vp(*[p.data_ptr() for p, _ in pairs]), vp(*[o.data_ptr() for _, o in pairs]), ip(*[x[0] for x in d]), ip(*[x[1] for x in d]),
+            ip(*[x[2] for x in d]), ip(*[x[3] for x in d]), lp(*[x[4] for x in d]))
 
 
 def colsum(*partials, outs=None):
@@ -184,7 +184,8 @@ def colsum(*partials, outs=None):
         _WG_BATCH["colsum"].extend(zip(parts, outs))
         it = iter(outs)
         return [None if p is None else next(it) for p in partials]
-    _lib.check(_call(("colsum_multi", tuple(int(p.numel()) for p in parts)), _cs_launch, list(zip(parts, outs)), _stream()),
+    args = _cs_args(list(zip(parts, outs)))
+    _lib.check(_call(("colsum_multi", tuple(int(p.numel()) for p in parts)), lib.kmu_colsum_multi_strided, *args, _stream()),
                "kmu_colsum_multi")
     it = iter(outs)
     return [None if p is None else next(it) for p in partials]
@@ -322,7 +323,7 @@ def _issue_batched(batch):
         ch = cs[i:i + 64]
         n = len(ch)
         vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
-        _lib.check(_cs_launch(ch, st), "kmu_colsum_multi")
+        _lib.check(lib.kmu_colsum_multi_strided(*_cs_args(ch), st), "kmu_colsum_multi")
 
 
 # ------------------------------------------------------------------------------------------ weight packs, once per step
