@@ -680,13 +680,15 @@ int kmu_mixer_fwd_stage(const float* x, const float* ln_weight, const float* ln_
  *   stage 3  pass B on the {B, dt} rows + dx of the C rows (conv3x3^T(dy; M_b), M_b read from `state` as the forward left it);
  *            the C-row sections of d_w_bcdt_partial / d_w_dw_partial ([.][N..2N)) are NOT written.
  * x = the mixer's input (the NORMALISED tensor kmu_mixer_fwd_stage returns in xn when it folds a LayerNorm); `state` must come from
- * kmu_mixer_fwd_stage.  Partial-row counts as kmu_hsmssd_bwd_stage_x3. */
+ * kmu_mixer_fwd_stage.  Partial-row counts as kmu_hsmssd_bwd_stage_x3.  wpk = the weight pack (kmu_hsmssd_pack_x3 / kmu_hsm_pack_multi) or
+ * NULL: with it stage 3 may run its contractions on the bf16 matrix core (csrc/hsmssd_bwdb.inc; kmu_mixer_debug_passb forces the choice). */
 size_t kmu_mixer_bwd_ws_bytes(int B, int C, int N, int Hs);
 int kmu_mixer_bwd_partials(int B, int C);
 int kmu_mixer_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
                         const float* w_out, const float* D, const float* state, float* dx, float* d_w_bcdt_partial, float* d_w_dw_partial,
                         float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial, float* d_wc_partial, float* d_dwc_partial, void* ws,
-                        size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, kmu_stream_t stream);
+                        size_t ws_bytes, int B, int C, int N, int Hs, int stage, int groups, const void* wpk, kmu_stream_t stream);
+void kmu_mixer_debug_passb(int mode);
 void kmu_mixer_debug_rows(int rows); /* tools only: force pass 1's configuration (H | 16: 8 waves | 32: wide tiles; 0 = automatic) */
 void kmu_conv_debug_split(int mode); /* tools only: K1 / KxK forward at small images: 0 automatic, 1 never split Cout tiles over workgroups, 2 always */
 

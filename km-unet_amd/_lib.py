@@ -155,7 +155,8 @@ SIGNATURES = {
     "kmu_mixer_fwd_stage": (_I, [_P] * 3 + [_c.c_float] + [_P] * 11 + [_Z, _P] + [_I] * 6 + [_P]),
     "kmu_mixer_bwd_ws_bytes": (_Z, [_I] * 4),
     "kmu_mixer_bwd_partials": (_I, [_I] * 2),
-    "kmu_mixer_bwd_stage": (_I, [_P] * 18 + [_Z] + [_I] * 6 + [_P]),
+    "kmu_mixer_bwd_stage": (_I, [_P] * 18 + [_Z] + [_I] * 6 + [_P, _P]),
+    "kmu_mixer_debug_passb": (None, [_I]),
     "kmu_mixer_debug_rows": (None, [_I]),
     "kmu_conv_debug_split": (None, [_I]),
     "kmu_gate_mlp_fwd_g": (_I, [_P] * 7 + [_I] * 7 + [_P]),

@@ -698,6 +698,7 @@ int fwd_impl(const float* x, const float* w_bcdt, const float* w_dw, const float
 #include "hsmssd_x3.inc"
 #include "hsmssd_v2.inc"
 #include "hsmssd_bwd.inc"
+#include "hsmssd_bwdb.inc"
 #include "hsmssd_bwdc.inc"
 
 // backward on the matrix core: ws = [partA | dhpre | delta | composite weights (fragment order) | transposed composite weights]
@@ -1036,12 +1037,15 @@ extern "C" size_t kmu_mixer_bwd_ws_bytes(int B, int C, int N, int Hs) {
     return C == 16 ? bwdc_ws_bytes<16>(B, Hs) : (C == 32 ? bwdc_ws_bytes<32>(B, Hs) : bwdc_ws_bytes<64>(B, Hs));
 }
 extern "C" int kmu_mixer_bwd_partials(int B, int C) { return B * (C / (C == 16 ? 2 : 4)); }
+// tools / tests: pass B of kmu_mixer_bwd_stage as hsm_bwd_passB(cmode) (0) or hsm_bwd_passB2 (1: contractions on the bf16 matrix core;
+// needs the weight pack and C in {16, 32}); -1 restores the default choice
+extern "C" void kmu_mixer_debug_passb(int mode) { g_passb2 = mode; }
 
 extern "C" int kmu_mixer_bwd_stage(const float* x, const float* dy, const float* dh, const float* w_bcdt, const float* w_dw, const float* w_hz,
                                    const float* w_out, const float* D, const float* state, float* dx, float* d_w_bcdt_partial,
                                    float* d_w_dw_partial, float* d_w_hz_partial, float* d_w_out_partial, float* d_D_partial,
                                    float* d_wc_partial, float* d_dwc_partial, void* ws, size_t ws_bytes, int B, int C, int N, int Hs, int stage,
-                                   int groups, kmu_stream_t stream) {
+                                   int groups, const void* wpk, kmu_stream_t stream) {
     KMU_REQUIRE(stage >= 0 && stage <= 3, "mixer_bwd_stage: stage must be 0 (correlation), 1 (C rows), 2 (gate) or 3 (pass B)");
     KMU_REQUIRE(x && dy && w_bcdt && w_dw && w_hz && w_out && D && state && dx && d_w_bcdt_partial && d_w_dw_partial && d_w_hz_partial &&
                     d_w_out_partial && d_D_partial && d_wc_partial && d_dwc_partial && ws,
@@ -1053,7 +1057,7 @@ extern "C" int kmu_mixer_bwd_stage(const float* x, const float* dy, const float*
     float* w = (float*)ws;
 #define KMU_BWDC_GO(CC)                                                                                                        \
     return bwdc_impl<CC>(x, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dx, d_w_bcdt_partial, d_w_dw_partial, d_w_hz_partial, \
-                         d_w_out_partial, d_D_partial, d_wc_partial, d_dwc_partial, w, B, Hs, 1 << stage, st, groups)
+                         d_w_out_partial, d_D_partial, d_wc_partial, d_dwc_partial, w, B, Hs, 1 << stage, st, groups, wpk)
     if (C == 16) KMU_BWDC_GO(16);
     if (C == 32) KMU_BWDC_GO(32);
     KMU_BWDC_GO(64);

@@ -812,10 +812,11 @@ def _mixer_backward(xn, dy, dh, w_bcdt, w_dw, w_hz, w_out, D, state, dims, pack_
     pc_W, pc_dw = mk(Pc, N, C), mk(Pc, N, 9)          # the C-row sections [:, N:2N] of p_bcdt / p_dw stay unwritten: these carry them
     nbytes = lib.kmu_mixer_bwd_ws_bytes(B, C, N, Hs)
     ws = torch.empty(max(1, (nbytes + 3) // 4), device=dev, dtype=torch.float32)
+    wpk = _hsm_pack(pack_ok, w_bcdt, w_dw, C, st, groups)
     for stage, nm in enumerate(_MIXER_BWD_STAGES):                                   # one kernel per call
         _lib.check(_call((nm + tag, (B, C, Hs)), lib.kmu_mixer_bwd_stage, _ptr(xn), _ptr(dy), _ptr(dh), _ptr(w_bcdt), _ptr(w_dw), _ptr(w_hz),
                          _ptr(w_out), _ptr(D), _ptr(state), _ptr(dx), _ptr(p_bcdt), _ptr(p_dw), _ptr(p_hz), _ptr(p_out), _ptr(p_D), _ptr(pc_W),
-                         _ptr(pc_dw), _ptr(ws), nbytes, B, C, N, Hs, stage, groups, st), "kmu_mixer_bwd_stage")
+                         _ptr(pc_dw), _ptr(ws), nbytes, B, C, N, Hs, stage, groups, _ptr(wpk), st), "kmu_mixer_bwd_stage")
     return dx, (p_bcdt, p_dw, p_hz, p_out, p_D, pc_W, pc_dw)
 
 

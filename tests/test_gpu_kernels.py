@@ -282,21 +282,28 @@ def test_mixer_backward_crows_as_dense_conv_matches_row_kernels(B, C, Hs):
     yo, ho = oh.hsmssd(xn, *w.values(), state_dim=N)
     ((yo * gy).sum() + (ho * gh).sum()).backward()
     ref = dict({k: v.grad for k, v in dict(w, lw=lw, lb=lb).items() if k != "A"}, x=x.grad)
+    from km_unet_amd import _lib
     saved, got = ops.MIXER_BWD_CROWS, {}
     try:
-        for mode in (64, 0):
+        for mode in (64, 65, 0):        # 64: dense-conv route with the fp32 pass B, 65: with pass B on the bf16 matrix core (C <= 32), 0: row kernels
+            if mode == 65 and C > 32:
+                continue
             ops.MIXER_BWD_CROWS = (16, 32, 64) if mode else ()
+            _lib.load().kmu_mixer_debug_passb({64: 0, 65: 1, 0: -1}[mode])
             xd = x.detach().to(DEV).requires_grad_(True)
             pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in dict(w, lw=lw, lb=lb).items()}
             y, h = ops.mixer_ln(xd, pd["lw"], pd["lb"], 1e-5, *[pd[k] for k in w])
             ((y * gy.to(DEV)).sum() + (h * gh.to(DEV)).sum()).backward()
             got[mode] = dict({k: v.grad for k, v in pd.items() if k != "A"}, x=xd.grad)
-            _report("mixer backward %s, C rows %s" % ((B, C, Hs), "as a dense conv" if mode else "in pass A / pass B"),
+            _report("mixer backward %s, C rows %s" % ((B, C, Hs), {64: "as a dense conv", 65: "as a dense conv, pass B split-bf16", 0: "in pass A / pass B"}[mode]),
                     **{"d_" + k: rel_err(got[mode][k], ref[k]) for k in ref})
     finally:
         ops.MIXER_BWD_CROWS = saved
-    errs = {k: rel_err(got[64][k], got[0][k]) for k in ref}
-    assert max(errs.values()) < 1e-4, errs
+        _lib.load().kmu_mixer_debug_passb(-1)
+    for mode in got:
+        if mode:
+            errs = {k: rel_err(got[mode][k], got[0][k]) for k in ref}
+            assert max(errs.values()) < 1e-4, (mode, errs)
 
 
 @pytest.mark.parametrize("name", ["k2_c16", "k2_c32", "k2_c64"])

@@ -66,7 +66,7 @@ def main():
             _lib.check(lib.kmu_mixer_bwd_stage(xn.data_ptr(), dy.data_ptr(), None, w_bcdt.data_ptr(), w_dw.data_ptr(), w_hz.data_ptr(), w_out.data_ptr(),
                                                D.data_ptr(), state.data_ptr(), dx.data_ptr(), p_bcdt.data_ptr(), p_dw.data_ptr(), p_hz.data_ptr(),
                                                p_out.data_ptr(), p_D.data_ptr(), pc_W.data_ptr(), pc_dw.data_ptr(), wsb.data_ptr(), nbb, B, C, N, Hs,
-                                               stage, G, st), "mixer bwd")
+                                               stage, G, wpk.data_ptr(), st), "mixer bwd")
 
         def old(stage):
             _lib.check(lib.kmu_hsmssd_bwd_stage_x3_pk(xn.data_ptr(), dy.data_ptr(), None, w_bcdt.data_ptr(), w_dw.data_ptr(), w_hz.data_ptr(),
@@ -77,6 +77,11 @@ def main():
         for i, nm in enumerate(("corr", "crows", "gate", "passB")):
             row["new_" + nm] = timed(lambda: new(i), args.iters)
         row["new_all"] = timed(lambda: [new(i) for i in range(4)], args.iters)
+        if C <= 32:
+            for mode, nm in ((0, "passB_fp32"), (1, "passB_x3")):
+                lib.kmu_mixer_debug_passb(mode)
+                row["new_" + nm] = timed(lambda: new(3), args.iters)
+            lib.kmu_mixer_debug_passb(-1)
         for i, nm in enumerate(("passA", "gate", "passB")):
             row["old_" + nm] = timed(lambda: old(i), args.iters)
         row["old_all"] = timed(lambda: [old(i) for i in range(3)], args.iters)
