@@ -415,6 +415,13 @@ int kmu_group_norm_fwd(const float* x, const float* gamma, const float* beta, fl
 int kmu_group_norm_bwd(const float* x, const float* gout, const float* gamma, const float* stats, float* dx,
                        float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW,
                        kmu_stream_t stream);
+/* the same with an activation folded in: act = 1: y = SiLU(GroupNorm(x)) (MultiScaleFusion's conv -> GroupNorm -> SiLU blocks,
+ * KM_UNetV3_SH.py:300-306); the backward multiplies gout by SiLU'(u), u re-derived from x, gamma, beta and the saved statistics */
+int kmu_group_norm_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* ws, int B, int C, int G,
+                           int HW, float eps, int act, kmu_stream_t stream);
+int kmu_group_norm_act_bwd(const float* x, const float* gout, const float* gamma, const float* beta, const float* stats, float* dx,
+                           float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW, int act,
+                           kmu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Split-bf16 ("bf16x3") matrix-core variants of the 3x3 convolutions (csrc/conv3x3_x3.hip): every fp32 operand is split

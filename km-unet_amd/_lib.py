@@ -105,6 +105,8 @@ SIGNATURES = {
     "kmu_group_norm_splits": (_I, [_I]),
     "kmu_group_norm_fwd": (_I, [_P] * 6 + [_I] * 4 + [_c.c_float, _P]),
     "kmu_group_norm_bwd": (_I, [_P] * 8 + [_I] * 4 + [_P]),
+    "kmu_group_norm_act_fwd": (_I, [_P] * 6 + [_I] * 4 + [_c.c_float, _I, _P]),
+    "kmu_group_norm_act_bwd": (_I, [_P] * 9 + [_I] * 5 + [_P]),
     "kmu_dwconv3x3_fwd": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_bwd_data": (_I, [_P] * 3 + [_I] * 4 + [_P]),
     "kmu_dwconv3x3_bwd_data_add": (_I, [_P] * 4 + [_I] * 4 + [_P]),

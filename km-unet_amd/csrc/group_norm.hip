@@ -58,6 +58,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 
 // fold the row's partials (double), normalise this block's slice; block (plane, 0) of the row's first channel
 // publishes (mean, rstd) for the backward
+// ACT = 1: y = SiLU(GroupNorm(x)) (MultiScaleFusion's blocks, KM_UNetV3_SH.py:300-306: conv -> GroupNorm -> SiLU); the backward kernels
+// then take g * SiLU'(u), u re-derived from x and the saved statistics with the forward's expression
+__device__ __forceinline__ float silu_f(float u) { return u / (1.f + __expf(-u)); }
+__device__ __forceinline__ float silu_grad(float u) {
+    const float s = 1.f / (1.f + __expf(-u));
+    return s * (1.f + u * (1.f - s));
+}
+template <int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ part,
                                                        float* __restrict__ y, float* __restrict__ stats, int C, int G,
@@ -86,22 +94,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
             floatx4 v = *reinterpret_cast<const floatx4*>(xp + p);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] * scale + shift;
+            for (int k = 0; k < 4; ++k) {
+                const float u = v[k] * scale + shift;
+                v[k] = ACT ? silu_f(u) : u;
+            }
             *reinterpret_cast<floatx4*>(yp + p) = v;
         }
     } else {
-        for (int p = p0 + threadIdx.x; p < p1; p += 256) yp[p] = xp[p] * scale + shift;
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            const float u = xp[p] * scale + shift;
+            yp[p] = ACT ? silu_f(u) : u;
+        }
     }
 }
 
 // part[(plane*S+s)*2 + {0,1}] = sum g, sum g*xhat
+template <int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ part,
                                                           int C, int G, int HW) {
     __shared__ float red[4];
     const int plane = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     const int b = plane / C, c = plane % C, grp = c / (C / G);
     const float mean = stats[(b * G + grp) * 2], rstd = stats[(b * G + grp) * 2 + 1];
+    const float scale = ACT ? gamma[c] * rstd : 0.f, shift = ACT ? beta[c] - mean * scale : 0.f;
     const int chunk = ((HW + S - 1) / S + 3) / 4 * 4, p0 = s * chunk, p1 = min(HW, p0 + chunk);
     const float* xp = x + (size_t)plane * HW;
     const float* gp = g + (size_t)plane * HW;
@@ -111,14 +128,16 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restric
             const floatx4 xv = *reinterpret_cast<const floatx4*>(xp + p), gv = *reinterpret_cast<const floatx4*>(gp + p);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                a += gv[k];
-                q += gv[k] * ((xv[k] - mean) * rstd);
+                const float ge = ACT ? gv[k] * silu_grad(xv[k] * scale + shift) : gv[k];
+                a += ge;
+                q += ge * ((xv[k] - mean) * rstd);
             }
         }
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-            a += gp[p];
-            q += gp[p] * ((xp[p] - mean) * rstd);
+            const float ge = ACT ? gp[p] * silu_grad(xp[p] * scale + shift) : gp[p];
+            a += ge;
+            q += ge * ((xp[p] - mean) * rstd);
         }
     }
     a = block_sum(a, red);
@@ -130,8 +149,9 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restric
 }
 
 // dx = rstd * (gamma_c*g - mean_row(gamma*g) - xhat * mean_row(gamma*g*xhat)); d_gamma/d_beta partial per (b, c)
+template <int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ part, float* __restrict__ dx,
                                                            float* __restrict__ dgamma_part,
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     }
     const double n = (double)cpg * HW;
     const float m0 = (float)(r0 / n), m1 = (float)(r1 / n), gc = gamma[c];
+    const float scale = ACT ? gc * rstd : 0.f, shift = ACT ? beta[c] - mean * scale : 0.f;
     const int chunk = ((HW + S - 1) / S + 3) / 4 * 4, p0 = s * chunk, p1 = min(HW, p0 + chunk);
     const float* xp = x + (size_t)plane * HW;
     const float* gp = g + (size_t)plane * HW;
@@ -170,11 +191,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             const floatx4 xv = *reinterpret_cast<const floatx4*>(xp + p), gv = *reinterpret_cast<const floatx4*>(gp + p);
             floatx4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = rstd * (gc * gv[k] - m0 - ((xv[k] - mean) * rstd) * m1);
+            for (int k = 0; k < 4; ++k) {
+                const float ge = ACT ? gv[k] * silu_grad(xv[k] * scale + shift) : gv[k];
+                o[k] = rstd * (gc * ge - m0 - ((xv[k] - mean) * rstd) * m1);
+            }
             *reinterpret_cast<floatx4*>(dp + p) = o;
         }
     } else {
-        for (int p = p0 + threadIdx.x; p < p1; p += 256) dp[p] = rstd * (gc * gp[p] - m0 - ((xp[p] - mean) * rstd) * m1);
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            const float ge = ACT ? gp[p] * silu_grad(xp[p] * scale + shift) : gp[p];
+            dp[p] = rstd * (gc * ge - m0 - ((xp[p] - mean) * rstd) * m1);
+        }
     }
 }
 
@@ -182,30 +209,48 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 
 extern "C" int kmu_group_norm_splits(int HW) { return splits_for(HW); }
 
-extern "C" int kmu_group_norm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
-                                  float* ws, int B, int C, int G, int HW, float eps, kmu_stream_t stream) {
+// act: 0 = GroupNorm, 1 = SiLU(GroupNorm(x)).  beta is needed by the backward when act != 0 (u is re-derived from x).
+extern "C" int kmu_group_norm_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* ws, int B, int C,
+                                      int G, int HW, float eps, int act, kmu_stream_t stream) {
     KMU_REQUIRE(x && gamma && beta && y && stats && ws, "group_norm_fwd: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, "group_norm_fwd: bad dims (C=%d, G=%d)", C, G);
+    KMU_REQUIRE(act == 0 || act == 1, "group_norm_fwd: act must be 0 (none) or 1 (SiLU)");
     hipStream_t st = (hipStream_t)stream;
     const int S = splits_for(HW);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * C, S), dim3(256), 0, st, x, ws, HW);
     int rc = kmu::launch_status("group_norm_fwd stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(B * C, S), dim3(256), 0, st, x, gamma, beta, ws, y, stats, C, G, HW, eps);
+    if (act) hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gamma, beta, ws, y, stats, C, G, HW, eps);
+    else hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(B * C, S), dim3(256), 0, st, x, gamma, beta, ws, y, stats, C, G, HW, eps);
     return kmu::launch_status("group_norm_fwd apply");
 }
+extern "C" int kmu_group_norm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                  float* ws, int B, int C, int G, int HW, float eps, kmu_stream_t stream) {
+    return kmu_group_norm_act_fwd(x, gamma, beta, y, stats, ws, B, C, G, HW, eps, 0, stream);
+}
 
+extern "C" int kmu_group_norm_act_bwd(const float* x, const float* gout, const float* gamma, const float* beta, const float* stats, float* dx,
+                                      float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW, int act,
+                                      kmu_stream_t stream) {
+    KMU_REQUIRE(x && gout && gamma && stats && dx && d_gamma_partial && d_beta_partial && ws, "group_norm_bwd: null pointer");
+    KMU_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, "group_norm_bwd: bad dims");
+    KMU_REQUIRE(act == 0 || (act == 1 && beta), "group_norm_bwd: act must be 0 or 1 (SiLU, which needs beta)");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = splits_for(HW);
+    if (act) hipLaunchKernelGGL(gn_bwd_sums_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, C, G, HW);
+    else hipLaunchKernelGGL(gn_bwd_sums_kernel<0>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, C, G, HW);
+    int rc = kmu::launch_status("group_norm_bwd sums");
+    if (rc) return rc;
+    if (act)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, dx, d_gamma_partial,
+                           d_beta_partial, C, G, HW);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, dx, d_gamma_partial,
+                           d_beta_partial, C, G, HW);
+    return kmu::launch_status("group_norm_bwd apply");
+}
 extern "C" int kmu_group_norm_bwd(const float* x, const float* gout, const float* gamma, const float* stats, float* dx,
                                   float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW,
                                   kmu_stream_t stream) {
-    KMU_REQUIRE(x && gout && gamma && stats && dx && d_gamma_partial && d_beta_partial && ws, "group_norm_bwd: null pointer");
-    KMU_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, "group_norm_bwd: bad dims");
-    hipStream_t st = (hipStream_t)stream;
-    const int S = splits_for(HW);
-    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(B * C, S), dim3(256), 0, st, x, gout, stats, ws, C, G, HW);
-    int rc = kmu::launch_status("group_norm_bwd sums");
-    if (rc) return rc;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, stats, ws, dx, d_gamma_partial,
-                       d_beta_partial, C, G, HW);
-    return kmu::launch_status("group_norm_bwd apply");
+    return kmu_group_norm_act_bwd(x, gout, gamma, nullptr, stats, dx, d_gamma_partial, d_beta_partial, ws, B, C, G, HW, 0, stream);
 }

@@ -313,7 +313,7 @@ class MultiScaleFusion(nn.Module):
         self.fusion = nn.Sequential(nn.Conv2d(co * 3, co, 1), nn.Conv2d(co, co, 3, padding=1), ChannelAttention(co, reduction))
 
     def forward(self, features):
-        x = torch.cat([F.silu(group_norm(conv3x3(f, blk[0]), blk[1])) for blk, f in zip(self.blocks, features)], dim=1)
+        x = torch.cat([group_norm(conv3x3(f, blk[0]), blk[1], silu=True) for blk, f in zip(self.blocks, features)], dim=1)
         return self.fusion[2](conv3x3(conv1x1(x, self.fusion[0]), self.fusion[1]))
 
 

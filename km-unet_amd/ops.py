@@ -2453,7 +2453,7 @@ class GroupNormFn(torch.autograd.Function):
     """nn.GroupNorm(G, C) forward/backward (KM_UNetV3_SH.py:57,271-273,294,448)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, G, eps):
+    def forward(ctx, x, gamma, beta, G, eps, act=0):
         lib = _lib.load()
         ctx.defer_wgrad = _leaf(gamma, beta)
         x, gamma, beta = _f32c(x, "x"), _f32c(gamma, "weight"), _f32c(beta, "bias")
@@ -2463,29 +2463,29 @@ class GroupNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty(B, G, 2, device=x.device, dtype=torch.float32)
         ws = torch.empty(B * C * S * 2, device=x.device, dtype=torch.float32)
-        _lib.check(_call(("group_norm_fwd", (B, C, G, HW)), lib.kmu_group_norm_fwd, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y),
-                         _ptr(stats), _ptr(ws), B, C, G, HW, float(eps), _stream()), "kmu_group_norm_fwd")
-        ctx.save_for_backward(x, gamma, stats)
-        ctx.cfg = (B, C, G, HW, S)
+        _lib.check(_call(("group_norm_fwd", (B, C, G, HW)), lib.kmu_group_norm_act_fwd, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y),
+                         _ptr(stats), _ptr(ws), B, C, G, HW, float(eps), int(act), _stream()), "kmu_group_norm_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (B, C, G, HW, S, int(act))
         return y
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, gamma, stats = ctx.saved_tensors
-        B, C, G, HW, S = ctx.cfg
+        x, gamma, beta, stats = ctx.saved_tensors
+        B, C, G, HW, S, act = ctx.cfg
         g = _f32c(g, "grad")
         dx = torch.empty_like(x)
         dgp = torch.empty(B, C, device=x.device, dtype=torch.float32)
         dbp = torch.empty(B, C, device=x.device, dtype=torch.float32)
         ws = torch.empty(B * C * S * 2, device=x.device, dtype=torch.float32)
-        _lib.check(_call(("group_norm_bwd", (B, C, G, HW)), lib.kmu_group_norm_bwd, _ptr(x), _ptr(g), _ptr(gamma), _ptr(stats),
-                         _ptr(dx), _ptr(dgp), _ptr(dbp), _ptr(ws), B, C, G, HW, _stream()), "kmu_group_norm_bwd")
+        _lib.check(_call(("group_norm_bwd", (B, C, G, HW)), lib.kmu_group_norm_act_bwd, _ptr(x), _ptr(g), _ptr(gamma), _ptr(beta), _ptr(stats),
+                         _ptr(dx), _ptr(dgp), _ptr(dbp), _ptr(ws), B, C, G, HW, act, _stream()), "kmu_group_norm_bwd")
         dg, db = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
         _wgrad(lambda: colsum(dgp, dbp, outs=[dg, db]), ctx.defer_wgrad)
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
-def group_norm(x, gn):
-    """gn: an nn.GroupNorm module (parameters + num_groups + eps)."""
-    return GroupNormFn.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps)
+def group_norm(x, gn, silu=False):
+    """gn: an nn.GroupNorm module (parameters + num_groups + eps); silu: SiLU folded into the normalisation kernels' epilogue."""
+    return GroupNormFn.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, int(silu))

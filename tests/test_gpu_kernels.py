@@ -620,6 +620,28 @@ def test_group_norm_vs_torch_cpu(B, C, G, H):
             dgamma=rel_err(md.weight.grad, m.weight.grad), dbeta=rel_err(md.bias.grad, m.bias.grad))
 
 
+@pytest.mark.parametrize("B,C,G,H", [(8, 32, 8, 32), (2, 16, 4, 7), (3, 32, 1, 12)])
+def test_group_norm_silu_vs_torch_cpu(B, C, G, H):
+    """SiLU(GroupNorm(x)) in the normalisation kernels' epilogue (MultiScaleFusion's blocks, KM_UNetV3_SH.py:300-306) against
+    F.silu(nn.GroupNorm(x)) in fp64 on the CPU: output, input gradient, both parameter gradients."""
+    import copy
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ops = _ops()
+    gen = torch.Generator().manual_seed(C * 3 + H)
+    x = (torch.randn(B, C, H, H, generator=gen, dtype=torch.float64) * 1.3 + 0.4).requires_grad_(True)
+    gy = torch.randn(B, C, H, H, generator=gen, dtype=torch.float64)
+    m = nn.GroupNorm(G, C).double()
+    with torch.no_grad():
+        m.weight.copy_(1 + 0.3 * torch.randn(C, generator=gen)); m.bias.copy_(0.2 * torch.randn(C, generator=gen))
+    md = copy.deepcopy(m).float().to(DEV)
+    yo = F.silu(m(x)); yo.backward(gy)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    y = ops.group_norm(xd, md, silu=True); y.backward(gy.float().to(DEV))
+    _report("group_norm + silu %s" % ((B, C, G, H),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad),
+            dgamma=rel_err(md.weight.grad, m.weight.grad), dbeta=rel_err(md.bias.grad, m.bias.grad))
+
+
 def test_qkv_gate_vs_torch_cpu():
     ops = _ops()
     gen = torch.Generator().manual_seed(5)
