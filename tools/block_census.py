@@ -9,14 +9,22 @@ torch.manual_seed(0)
 dev = "cuda"
 m = km_unet_amd.KM_UNetV3(num_classes=5).to(dev).train()
 name = sys.argv[1]
-mod, shape = {"bridge": (m.bridge_attention, (8, 64, 16, 16)), "lca1": (m.lca1, (8, 16, 64, 64)), "kan1": (m.enc1[0], (8, 16, 128, 128)),
+mod, shape = {"msf1": (None, None), "bridge": (m.bridge_attention, (8, 64, 16, 16)), "lca1": (m.lca1, (8, 16, 64, 64)), "kan1": (m.enc1[0], (8, 16, 128, 128)),
               "iwp1": (m.enc1[2], (8, 16, 128, 128)), "dec1": (m.dec1, (8, 64, 16, 16)), "vim32": (m.enc2[1], (8, 32, 64, 64)), "vim64": (m.enc3[1], (8, 64, 32, 32)),
               "vim16": (m.enc1[1], (8, 16, 128, 128)), "kan3": (m.enc3[0], (8, 32, 32, 32))}[name]
-x = torch.randn(*shape, device=dev, requires_grad=True)
-params = [p for p in mod.parameters() if p.requires_grad]
-def step():
-    y = mod(x)
-    return torch.autograd.grad(y.float().square().mean(), [x] + params, allow_unused=True)
+if name == "msf1":
+    feats = [torch.randn(8, c, 32, 32, device=dev, requires_grad=True) for c in (16, 32, 32)]
+    inner = m.attention1[0]
+    params = [p for p in inner.parameters() if p.requires_grad]
+    def step():
+        y = inner(list(feats))
+        return torch.autograd.grad(y.float().square().mean(), feats + params, allow_unused=True)
+else:
+    x = torch.randn(*shape, device=dev, requires_grad=True)
+    params = [p for p in mod.parameters() if p.requires_grad]
+    def step():
+        y = mod(x)
+        return torch.autograd.grad(y.float().square().mean(), [x] + params, allow_unused=True)
 for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
