@@ -13,7 +13,8 @@
 //   backward  B0  BN_f sums;  B1  dz, d[deform + x], df -> BN_v / BN_r sums, d W_f;  B2  dv_pre, dr_pre -> d W_v, dx, dagg -> BN_a sums,
 //             BN_e sums, d w_r;  B3  da_pre, du_pre -> d w_a, d W_e, de, dx;  B4  dx = edge adjoint (gather) + the other dx pieces.
 //
-// Workgroup = 32 consecutive pixels of one sample (all channels), 256 threads.  Every kernel leaves its BatchNorm sums as per-workgroup
+// Workgroup = TP = 16 consecutive pixels of one sample (all channels), 256 threads (128 workgroups at [8,64,16,16]; 32-pixel tiles: 64
+// workgroups, every kernel ~40 % slower).  Every kernel leaves its BatchNorm sums as per-workgroup
 // partial rows and every workgroup of the NEXT kernel folds them in a fixed order in double: deterministic, no atomics, no separate
 // statistics launch.  The BatchNorm1d layers act on rows whose layout differs from NCHW only by a permutation, so they are per-channel
 // (BN_v, BN_e) or single-feature (BN_a, BN_r) statistics over the same elements.  ReLU branches are decided by ONE expression,
@@ -24,7 +25,12 @@ using kmu::floatx4;
 
 namespace {
 
-constexpr int TP = 32;            // pixels per workgroup
+#ifndef KMU_DAGEM_TP
+#define KMU_DAGEM_TP 16
+#endif
+constexpr int TP = KMU_DAGEM_TP;  // pixels per workgroup (16 or 32)
+constexpr int TPS = TP == 32 ? 5 : 4, NGR = 256 / TP;      // thread = (pixel p = tid % TP, group g = tid / TP)
+static_assert(TP == 16 || TP == 32, "tile of 16 or 32 pixels");
 enum { BN_A = 0, BN_V = 1, BN_E = 2, BN_R = 3, BN_F = 4 };
 
 __device__ __forceinline__ float relu_bn(float pre, float scale, float shift) { return fmaxf(fmaf(pre, scale, shift), 0.f); }
@@ -165,10 +171,10 @@ __device__ __forceinline__ void bn_bwd_coeffs(const kmu_dagem_args& a, int which
     __syncthreads();
 }
 
-// sum of v over the 32 pixel lanes of a half-wave (lanes p = tid & 31); every lane gets the total
+// sum of v over the TP pixel lanes of a thread group (lanes p = tid % TP); every lane gets the total
 __device__ __forceinline__ float sum32(float v) {
 #pragma unroll
-    for (int m = 16; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    for (int m = TP / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
 // block total of two values (256 threads); result valid in thread 0
@@ -209,7 +215,7 @@ __device__ __forceinline__ void load_tile(float* dst, const float* __restrict__ 
         float v[LB];
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
-            const int i = i0 + u * 256, c = i >> 5, p = i & 31;
+            const int i = i0 + u * 256, c = i >> TPS, p = i & (TP - 1);
             v[u] = (i < n && p < t.np) ? s[(size_t)c * P + p] : 0.f;
         }
 #pragma unroll
@@ -217,9 +223,9 @@ __device__ __forceinline__ void load_tile(float* dst, const float* __restrict__ 
             if (i0 + u * 256 < n) dst[i0 + u * 256] = v[u];
     }
 }
-// the pixel's own value and its four cyclic neighbours (DAGEM_md.py:57-60: rows -1 / +1, columns -1 / +1): xs[k5][c][32]
+// the pixel's own value and its four cyclic neighbours (DAGEM_md.py:57-60: rows -1 / +1, columns -1 / +1): xs[k5][c][TP]
 __device__ __forceinline__ void load_tile5(float* xs, const float* __restrict__ x, int C, int H, int W, const Tile& t) {
-    const int P = H * W, p = threadIdx.x & 31;
+    const int P = H * W, p = threadIdx.x & (TP - 1);
     const float* s = x + (size_t)t.b * C * P;
     int q[5];
     {
@@ -231,21 +237,21 @@ __device__ __forceinline__ void load_tile5(float* xs, const float* __restrict__ 
         q[4] = h * W + (w == W - 1 ? 0 : w + 1);
     }
     const bool ok = p < t.np;
-    // thread = (pixel p, channel phase tid >> 5): channels c = (tid >> 5) + 8 j, all five positions of LB / ... channels in flight
-    for (int c0 = threadIdx.x >> 5; c0 < C; c0 += 8 * 2) {
+    // thread = (pixel p, channel phase tid >> TPS): channels c = (tid >> TPS) + 8 j, all five positions of LB / ... channels in flight
+    for (int c0 = threadIdx.x >> TPS; c0 < C; c0 += NGR * 2) {
         float v[2][5];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const int c = c0 + 8 * u;
+                const int c = c0 + NGR * u;
                 v[u][k] = (ok && c < C) ? s[(size_t)c * P + q[k]] : 0.f;
             }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const int c = c0 + 8 * u;
+                const int c = c0 + NGR * u;
                 if (c < C) xs[(k * C + c) * TP + p] = v[u][k];
             }
     }
@@ -259,7 +265,7 @@ __device__ __forceinline__ void tile_apply(float* dst, int nch, int P, const Til
         float v[UB][NS];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int i = i0 + u * 256, c = i >> 5, p = i & 31;
+            const int i = i0 + u * 256, c = i >> TPS, p = i & (TP - 1);
             const bool ok = i < n && p < t.np;
 #pragma unroll
             for (int k = 0; k < NS; ++k) v[u][k] = ok ? src[k][((size_t)t.b * nch + c) * P + t.gp0 + p] : 0.f;
@@ -267,7 +273,7 @@ __device__ __forceinline__ void tile_apply(float* dst, int nch, int P, const Til
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int i = i0 + u * 256;
-            if (i < n) dst[i] = (i & 31) < t.np ? op(i >> 5, i & 31, v[u]) : 0.f;
+            if (i < n) dst[i] = (i & (TP - 1)) < t.np ? op(i >> TPS, i & (TP - 1), v[u]) : 0.f;
         }
     }
 }
@@ -286,7 +292,7 @@ __device__ __forceinline__ void load_vec(float* dst, const float* __restrict__ s
 // F0: a_pre [B,C,P], u_pre [B,C2,P,4]; partial sums of BN_a (1 feature) and BN_e (C2 features)
 template <int C>
 __global__ __launch_bounds__(256) void dagem_f0(kmu_dagem_args a) {
-    constexpr int C2 = C / 2, OPT = C2 / 8;
+    constexpr int C2 = C / 2, OPT = C2 / NGR;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* xs = sm;                       // [5][C][32]
     float* we = xs + 5 * C * TP;          // [C2][2C]
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void dagem_f0(kmu_dagem_args a) {
         const float w0 = a.wa[0], w1 = a.wa[1], w2 = a.wa[2], w3 = a.wa[3], b0 = a.ba[0];
         float s = 0.f, q = 0.f;
         for (int i = tid; i < C * TP; i += 256) {
-            const int c = i >> 5, p = i & 31;
+            const int c = i >> TPS, p = i & (TP - 1);
             if (p < t.np) {
                 const float x0 = xs[i];
                 const float v = b0 + w0 * (x0 * xs[C * TP + i]) + w1 * (x0 * xs[2 * C * TP + i]) + w2 * (x0 * xs[3 * C * TP + i]) +
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void dagem_f0(kmu_dagem_args a) {
         }
     }
     {   // edge update pre-activation: thread = (pixel p, output group g)
-        const int p = tid & 31, g = tid >> 5;
+        const int p = tid & (TP - 1), g = tid >> TPS;
         float base[OPT], u[OPT][4];
 #pragma unroll
         for (int j = 0; j < OPT; ++j) {
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void dagem_f0(kmu_dagem_args a) {
 // F1: v_pre, r_pre [B,C2,P]; partial sums of BN_v (C2) and BN_r (1)
 template <int C>
 __global__ __launch_bounds__(256) void dagem_f1(kmu_dagem_args a, int NWG) {
-    constexpr int C2 = C / 2, OPT = C2 / 8;
+    constexpr int C2 = C / 2, OPT = C2 / NGR;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     double* tmp = reinterpret_cast<double*>(sm);           // [2 * C2]
     double* red = tmp + 2 * C;                              // [512]
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void dagem_f1(kmu_dagem_args a, int NWG) {
     }
     __syncthreads();
     float* part = a.part + t.wg * part_stride(C);
-    const int p = tid & 31, g = tid >> 5;
+    const int p = tid & (TP - 1), g = tid >> TPS;
     const bool ok = p < t.np;
     {   // vertex update pre-activation
         float acc[OPT];
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256) void dagem_f1(kmu_dagem_args a, int NWG) {
 // F2: z [B,C,P] = W_f . [dconv + x | ReLU(BN_v(v_pre)) ReLU(BN_r(r_pre))]; partial sums of BN_f (C)
 template <int C>
 __global__ __launch_bounds__(256) void dagem_f2(kmu_dagem_args a, int NWG) {
-    constexpr int C2 = C / 2, KF = C + C2, OPT = C / 8;
+    constexpr int C2 = C / 2, KF = C + C2, OPT = C / NGR;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     double* tmp = reinterpret_cast<double*>(sm);
     double* red = tmp + 2 * C;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(256) void dagem_f2(kmu_dagem_args a, int NWG) {
     }
     __syncthreads();
     float* part = a.part + t.wg * part_stride(C);
-    const int p = tid & 31, g = tid >> 5;
+    const int p = tid & (TP - 1), g = tid >> TPS;
     const bool ok = p < t.np;
     float acc[OPT];
 #pragma unroll
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(256) void dagem_f3(kmu_dagem_args a, int NWG) {
     const Tile t = tile_of(a);
     bn_coeffs<C>(a, BN_F, a.part, NWG, (double)a.B * P, blockIdx.x == 0, sc, sh, tmp, red);
     for (int i = threadIdx.x; i < C * TP; i += 256) {
-        const int c = i >> 5, p = i & 31;
+        const int c = i >> TPS, p = i & (TP - 1);
         if (p < t.np) {
             const size_t idx = ((size_t)t.b * C + c) * P + t.gp0 + p;
             a.out[idx] = relu_bn(a.z[idx], sc[c], sh[c]);
@@ -524,10 +530,10 @@ __global__ __launch_bounds__(256) void dagem_f3(kmu_dagem_args a, int NWG) {
 // B0: partial (sum g', sum g' zhat) of BN_f, g' = g . [out > 0]
 template <int C>
 __global__ __launch_bounds__(256) void dagem_b0(kmu_dagem_args a) {
-    const int P = a.H * a.W, p = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int P = a.H * a.W, p = threadIdx.x & (TP - 1), g = threadIdx.x >> TPS;
     const Tile t = tile_of(a);
     float* part = a.part_bwd + t.wg * part_stride(C);
-    for (int o = g; o < C; o += 8) {
+    for (int o = g; o < C; o += NGR) {
         const float mu = a.bnstat[(BN_F * C + o) * 2], rs = a.bnstat[(BN_F * C + o) * 2 + 1];
         const float sc = a.gamma[BN_F][o] * rs, sh = a.beta[BN_F][o] - mu * sc;
         float s1 = 0.f, s2 = 0.f;
@@ -580,9 +586,9 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
         });
     }
     // vert / ue of this tile (registers of the threads that own (o, p) below) and f into `in`
-    const int p = tid & 31, g = tid >> 5;
+    const int p = tid & (TP - 1), g = tid >> TPS;
     const bool ok = p < t.np;
-    constexpr int OPT = C2 / 8;
+    constexpr int OPT = C2 / NGR;
     float vert[OPT], ue[OPT], vhat[OPT], rhat[OPT];
     const float muR = a.bnstat[(BN_R * C) * 2], rsR = a.bnstat[(BN_R * C) * 2 + 1];
     const float scR = a.gamma[BN_R][0] * rsR, shR = a.beta[BN_R][0] - muR * scR;
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
     __syncthreads();
     // d(dconv + x)[c][p] = sum_o W_f[o][c] dz[o][p]: thread = (p, 8 channel groups)
     {
-        constexpr int CPT = C / 8;
+        constexpr int CPT = C / NGR;
         float acc[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(256) void dagem_b1(kmu_dagem_args a, int NWG) {
 // B2: dv_pre -> d W_v / d b_v partial rows, dx piece, dagg -> ga [B,C,P] + BN_a sums; dr_pre [B,C2,P] -> d w_r / d b_r partials, BN_e sums
 template <int C>
 __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
-    constexpr int C2 = C / 2, OPT = C2 / 8;
+    constexpr int C2 = C / 2, OPT = C2 / NGR;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     double* tmp = reinterpret_cast<double*>(sm);
     double* red = tmp + 2 * C;
@@ -709,10 +715,10 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
     }
     __syncthreads();
     float* part = a.part_bwd + t.wg * part_stride(C);
-    const int p = tid & 31, g = tid >> 5;
+    const int p = tid & (TP - 1), g = tid >> TPS;
     const bool ok = p < t.np;
     {   // dx piece and dagg: [c][p] = sum_o W_v[o][c (+C)] dv[o][p]; thread = (p, 8 channel groups)
-        constexpr int CPT = C / 8;
+        constexpr int CPT = C / NGR;
         float ax[CPT], ag[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) ax[j] = ag[j] = 0.f;
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(256) void dagem_b2(kmu_dagem_args a, int NWG) {
 // B3: da_pre, du_pre -> d w_a / d b_a, d W_e / d b_e partial rows, de [B,C,P,4], dx piece added into dxb
 template <int C>
 __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
-    constexpr int C2 = C / 2, OPT = C2 / 8;
+    constexpr int C2 = C / 2, OPT = C2 / NGR;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     double* tmp = reinterpret_cast<double*>(sm);
     double* red = tmp + 2 * C;
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
     bn_bwd_coeffs<1>(a, BN_A, a.part_bwd, NWG, (double)a.B * C * P, writer, ca, ca + 1, ca + 2, ca + 3, ca + 4, ca + 5, tmp, red);
     load_tile5(xs, a.x, C, a.H, a.W, t);
     load_vec(we, a.we, C2 * 2 * C);
-    const int p = tid & 31, g = tid >> 5;
+    const int p = tid & (TP - 1), g = tid >> TPS;
     const bool ok = p < t.np;
     {   // du_pre[o][p][k] into LDS
         const float w0 = a.wr[0], w1 = a.wr[1], w2 = a.wr[2], w3 = a.wr[3];
@@ -852,7 +858,7 @@ __global__ __launch_bounds__(256) void dagem_b3(kmu_dagem_args a, int NWG) {
     }
     __syncthreads();
     {   // per (c, p): da_pre, de = w_a da_pre + sum_o W_e[o][C + c] du[o][p][.], dx += sum_o W_e[o][c] sum_k du; thread = (p, 8 channel groups)
-        constexpr int CPT = C / 8;
+        constexpr int CPT = C / NGR;
         const float mA1 = ca[0], mA2 = ca[1], muA = ca[2], rsA = ca[3], scA = ca[4];
         const float wa0 = a.wa[0], wa1 = a.wa[1], wa2 = a.wa[2], wa3 = a.wa[3];
         float was[4] = {0.f, 0.f, 0.f, 0.f}, bas = 0.f;
