@@ -416,7 +416,8 @@ int kmu_group_norm_bwd(const float* x, const float* gout, const float* gamma, co
                        float* d_gamma_partial, float* d_beta_partial, float* ws, int B, int C, int G, int HW,
                        kmu_stream_t stream);
 /* the same with an activation folded in: act = 1: y = SiLU(GroupNorm(x)) (MultiScaleFusion's conv -> GroupNorm -> SiLU blocks,
- * KM_UNetV3_SH.py:300-306); the backward multiplies gout by SiLU'(u), u re-derived from x, gamma, beta and the saved statistics */
+ * KM_UNetV3_SH.py:300-306), act = 2: y = sigmoid(GroupNorm(x)) (the output head, :516-517); the backward multiplies gout by act'(u),
+ * u re-derived from x, gamma, beta and the saved statistics */
 int kmu_group_norm_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* ws, int B, int C, int G,
                            int HW, float eps, int act, kmu_stream_t stream);
 int kmu_group_norm_act_bwd(const float* x, const float* gout, const float* gamma, const float* beta, const float* stats, float* dx,

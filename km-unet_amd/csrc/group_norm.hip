@@ -65,6 +65,18 @@ __device__ __forceinline__ float silu_grad(float u) {
     const float s = 1.f / (1.f + __expf(-u));
     return s * (1.f + u * (1.f - s));
 }
+// ACT = 2: y = sigmoid(GroupNorm(x)) (the model's output head, KM_UNetV3_SH.py:516-517)
+template <int ACT>
+__device__ __forceinline__ float act_f(float u) { return ACT == 1 ? silu_f(u) : (ACT == 2 ? 1.f / (1.f + __expf(-u)) : u); }
+template <int ACT>
+__device__ __forceinline__ float act_grad(float u) {
+    if (ACT == 1) return silu_grad(u);
+    if (ACT == 2) {
+        const float s = 1.f / (1.f + __expf(-u));
+        return s * (1.f - s);
+    }
+    return 1.f;
+}
 template <int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ part,
@@ -96,14 +108,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float u = v[k] * scale + shift;
-                v[k] = ACT ? silu_f(u) : u;
+                v[k] = act_f<ACT>(u);
             }
             *reinterpret_cast<floatx4*>(yp + p) = v;
         }
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
             const float u = xp[p] * scale + shift;
-            yp[p] = ACT ? silu_f(u) : u;
+            yp[p] = act_f<ACT>(u);
         }
     }
 }
@@ -128,14 +140,14 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restric
             const floatx4 xv = *reinterpret_cast<const floatx4*>(xp + p), gv = *reinterpret_cast<const floatx4*>(gp + p);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float ge = ACT ? gv[k] * silu_grad(xv[k] * scale + shift) : gv[k];
+                const float ge = ACT ? gv[k] * act_grad<ACT>(xv[k] * scale + shift) : gv[k];
                 a += ge;
                 q += ge * ((xv[k] - mean) * rstd);
             }
         }
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-            const float ge = ACT ? gp[p] * silu_grad(xp[p] * scale + shift) : gp[p];
+            const float ge = ACT ? gp[p] * act_grad<ACT>(xp[p] * scale + shift) : gp[p];
             a += ge;
             q += ge * ((xp[p] - mean) * rstd);
         }
@@ -192,14 +204,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             floatx4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float ge = ACT ? gv[k] * silu_grad(xv[k] * scale + shift) : gv[k];
+                const float ge = ACT ? gv[k] * act_grad<ACT>(xv[k] * scale + shift) : gv[k];
                 o[k] = rstd * (gc * ge - m0 - ((xv[k] - mean) * rstd) * m1);
             }
             *reinterpret_cast<floatx4*>(dp + p) = o;
         }
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-            const float ge = ACT ? gp[p] * silu_grad(xp[p] * scale + shift) : gp[p];
+            const float ge = ACT ? gp[p] * act_grad<ACT>(xp[p] * scale + shift) : gp[p];
             dp[p] = rstd * (gc * ge - m0 - ((xp[p] - mean) * rstd) * m1);
         }
     }
@@ -209,18 +221,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 
 extern "C" int kmu_group_norm_splits(int HW) { return splits_for(HW); }
 
-// act: 0 = GroupNorm, 1 = SiLU(GroupNorm(x)).  beta is needed by the backward when act != 0 (u is re-derived from x).
+// act: 0 = GroupNorm, 1 = SiLU(GroupNorm(x)), 2 = sigmoid(GroupNorm(x)).  beta is needed by the backward when act != 0 (u is re-derived from x).
 extern "C" int kmu_group_norm_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* ws, int B, int C,
                                       int G, int HW, float eps, int act, kmu_stream_t stream) {
     KMU_REQUIRE(x && gamma && beta && y && stats && ws, "group_norm_fwd: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, "group_norm_fwd: bad dims (C=%d, G=%d)", C, G);
-    KMU_REQUIRE(act == 0 || act == 1, "group_norm_fwd: act must be 0 (none) or 1 (SiLU)");
+    KMU_REQUIRE(act >= 0 && act <= 2, "group_norm_fwd: act must be 0 (none), 1 (SiLU) or 2 (sigmoid)");
     hipStream_t st = (hipStream_t)stream;
     const int S = splits_for(HW);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * C, S), dim3(256), 0, st, x, ws, HW);
     int rc = kmu::launch_status("group_norm_fwd stats");
     if (rc) return rc;
-    if (act) hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gamma, beta, ws, y, stats, C, G, HW, eps);
+    if (act == 1) hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gamma, beta, ws, y, stats, C, G, HW, eps);
+    else if (act == 2) hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(B * C, S), dim3(256), 0, st, x, gamma, beta, ws, y, stats, C, G, HW, eps);
     else hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(B * C, S), dim3(256), 0, st, x, gamma, beta, ws, y, stats, C, G, HW, eps);
     return kmu::launch_status("group_norm_fwd apply");
 }
@@ -234,15 +247,19 @@ extern "C" int kmu_group_norm_act_bwd(const float* x, const float* gout, const f
                                       kmu_stream_t stream) {
     KMU_REQUIRE(x && gout && gamma && stats && dx && d_gamma_partial && d_beta_partial && ws, "group_norm_bwd: null pointer");
     KMU_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, "group_norm_bwd: bad dims");
-    KMU_REQUIRE(act == 0 || (act == 1 && beta), "group_norm_bwd: act must be 0 or 1 (SiLU, which needs beta)");
+    KMU_REQUIRE(act == 0 || ((act == 1 || act == 2) && beta), "group_norm_bwd: act must be 0, 1 (SiLU) or 2 (sigmoid); 1 / 2 need beta");
     hipStream_t st = (hipStream_t)stream;
     const int S = splits_for(HW);
-    if (act) hipLaunchKernelGGL(gn_bwd_sums_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, C, G, HW);
+    if (act == 1) hipLaunchKernelGGL(gn_bwd_sums_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, C, G, HW);
+    else if (act == 2) hipLaunchKernelGGL(gn_bwd_sums_kernel<2>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, C, G, HW);
     else hipLaunchKernelGGL(gn_bwd_sums_kernel<0>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, C, G, HW);
     int rc = kmu::launch_status("group_norm_bwd sums");
     if (rc) return rc;
-    if (act)
+    if (act == 1)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, dx, d_gamma_partial,
+                           d_beta_partial, C, G, HW);
+    else if (act == 2)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<2>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, dx, d_gamma_partial,
                            d_beta_partial, C, G, HW);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(B * C, S), dim3(256), 0, st, x, gout, gamma, beta, stats, ws, dx, d_gamma_partial,

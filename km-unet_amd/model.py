@@ -416,4 +416,6 @@ class KM_UNetV3(nn.Module):
         d2 = self.dec2[2](conv3x3(self.dec2[0](d1), self.dec2[1]))
         d2 = torch.cat([d2, self._joined(pyr[1], self.attention2, e1p[1], e2p[1], d2)], dim=1)
         d3 = conv3x3(self.dec3[2](conv3x3(self.dec3[0](d2), self.dec3[1])), self.dec3[3])
+        if isinstance(self.activation, nn.Sigmoid):
+            return group_norm(d3, self.output_norm, sigmoid=True)       # the sigmoid rides in the normalisation kernels' epilogue
         return self.activation(group_norm(d3, self.output_norm))

@@ -63,11 +63,13 @@ def gate_mlp(p, lin1, lin2, act1, act2="sigmoid"):
     return ops.gate_mlp(p, lin1.weight, lin1.bias, lin2.weight, lin2.bias, act1, act2)
 
 
-def group_norm(x, gn, silu=False):
-    """nn.GroupNorm (+ SiLU, MultiScaleFusion's blocks) through the HIP kernels (csrc/group_norm.hip); KMU_GLUE_TORCH=group_norm keeps ATen's."""
+def group_norm(x, gn, silu=False, sigmoid=False):
+    """nn.GroupNorm (+ SiLU: MultiScaleFusion's blocks; + sigmoid: the output head) through the HIP kernels (csrc/group_norm.hip);
+    KMU_GLUE_TORCH=group_norm keeps ATen's."""
     if "group_norm" in _TORCH_GLUE or not x.is_cuda:
-        return F.silu(gn(x)) if silu else gn(x)
-    return ops.group_norm(x, gn, silu)
+        y = gn(x)
+        return F.silu(y) if silu else (torch.sigmoid(y) if sigmoid else y)
+    return ops.group_norm(x, gn, silu, sigmoid)
 
 
 def _is_pointwise(c):

@@ -2486,6 +2486,7 @@ class GroupNormFn(torch.autograd.Function):
         return dx, dg, db, None, None, None
 
 
-def group_norm(x, gn, silu=False):
-    """gn: an nn.GroupNorm module (parameters + num_groups + eps); silu: SiLU folded into the normalisation kernels' epilogue."""
-    return GroupNormFn.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, int(silu))
+def group_norm(x, gn, silu=False, sigmoid=False):
+    """gn: an nn.GroupNorm module (parameters + num_groups + eps); silu / sigmoid: the activation folded into the normalisation kernels'
+    epilogue (and its derivative into the backward kernels)."""
+    return GroupNormFn.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, 1 if silu else (2 if sigmoid else 0))

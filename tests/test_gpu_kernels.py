@@ -620,10 +620,11 @@ def test_group_norm_vs_torch_cpu(B, C, G, H):
             dgamma=rel_err(md.weight.grad, m.weight.grad), dbeta=rel_err(md.bias.grad, m.bias.grad))
 
 
-@pytest.mark.parametrize("B,C,G,H", [(8, 32, 8, 32), (2, 16, 4, 7), (3, 32, 1, 12)])
-def test_group_norm_silu_vs_torch_cpu(B, C, G, H):
-    """SiLU(GroupNorm(x)) in the normalisation kernels' epilogue (MultiScaleFusion's blocks, KM_UNetV3_SH.py:300-306) against
-    F.silu(nn.GroupNorm(x)) in fp64 on the CPU: output, input gradient, both parameter gradients."""
+@pytest.mark.parametrize("B,C,G,H,act", [(8, 32, 8, 32, "silu"), (2, 16, 4, 7, "silu"), (3, 32, 1, 12, "silu"), (8, 5, 1, 128, "sigmoid"),
+                                          (2, 7, 1, 9, "sigmoid")])
+def test_group_norm_silu_vs_torch_cpu(B, C, G, H, act):
+    """act(GroupNorm(x)) in the normalisation kernels' epilogue -- SiLU (MultiScaleFusion's blocks, KM_UNetV3_SH.py:300-306) and sigmoid
+    (the output head, :516-517) -- against torch in fp64 on the CPU: output, input gradient, both parameter gradients."""
     import copy
     import torch.nn as nn
     import torch.nn.functional as F
@@ -635,10 +636,10 @@ def test_group_norm_silu_vs_torch_cpu(B, C, G, H):
     with torch.no_grad():
         m.weight.copy_(1 + 0.3 * torch.randn(C, generator=gen)); m.bias.copy_(0.2 * torch.randn(C, generator=gen))
     md = copy.deepcopy(m).float().to(DEV)
-    yo = F.silu(m(x)); yo.backward(gy)
+    yo = F.silu(m(x)) if act == "silu" else torch.sigmoid(m(x)); yo.backward(gy)
     xd = x.detach().float().to(DEV).requires_grad_(True)
-    y = ops.group_norm(xd, md, silu=True); y.backward(gy.float().to(DEV))
-    _report("group_norm + silu %s" % ((B, C, G, H),), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad),
+    y = ops.group_norm(xd, md, silu=act == "silu", sigmoid=act == "sigmoid"); y.backward(gy.float().to(DEV))
+    _report("group_norm + %s %s" % (act, (B, C, G, H)), y=rel_err(y, yo), dx=rel_err(xd.grad, x.grad),
             dgamma=rel_err(md.weight.grad, m.weight.grad), dbeta=rel_err(md.bias.grad, m.bias.grad))
 
 
