@@ -219,3 +219,27 @@ def test_bench_kernel_model_covers_every_recorded_entry_point():
     # the round-4 names resolve to their own models
     assert b.kernel_model("hsmssd_fwd_pass1_v2", [8, 16, 128])[2] == 4.0 * 8 * 16 * 128 * 128
     assert b.kernel_model("hsmssd_bwd_passB_g", [24, 64, 32])[1] > 0
+
+
+def test_colsum_row_layout_descriptors():
+    """ops._cs_desc (host logic of kmu_colsum_multi_strided): packed partial rows, a column range of a wider partial array (the B / dt
+    sections of pass B's [., 3N, C] slabs), the rows of one weight group of a grouped launch's [samples / G][G][tiles] partials -- and
+    the layouts it must refuse."""
+    import pytest
+    import torch
+    from km_unet_amd import ops
+    N, C, P = 64, 16, 12
+    p = torch.zeros(P, 3 * N, C)
+    assert ops._cs_desc(p, torch.zeros(3 * N, C)) == (P, 3 * N * C, 3 * N * C, P, 0)
+    assert ops._cs_desc(p[:, :N], torch.zeros(N, C)) == (P, N * C, 3 * N * C, P, 0)                       # column range: row stride > cols
+    assert ops._cs_desc(p[:, 2 * N:], torch.zeros(N, C)) == (P, N * C, 3 * N * C, P, 0)
+    Bs, G, tb = 2, 3, 2
+    g = torch.zeros(Bs * G * tb, 3 * N, C).view(Bs, G, tb, 3 * N, C)[:, 1]                                # one group's rows: runs of tb
+    assert ops._cs_desc(g, torch.zeros(3 * N, C)) == (Bs * tb, 3 * N * C, 3 * N * C, tb, G * tb * 3 * N * C)
+    assert ops._cs_desc(g[:, :, :N], torch.zeros(N, C)) == (Bs * tb, N * C, 3 * N * C, tb, G * tb * 3 * N * C)
+    one = torch.zeros(1, 5)
+    assert ops._cs_desc(one, torch.zeros(5)) == (1, 5, 5, 1, 0)
+    with pytest.raises(RuntimeError):
+        ops._cs_desc(p[:, :, ::2], torch.zeros(3 * N, C // 2))                                            # rows not contiguous
+    with pytest.raises(RuntimeError):
+        ops._cs_desc(torch.zeros(4, 6), torch.zeros(5))                                                   # sizes do not divide
